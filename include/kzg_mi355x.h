@@ -1,0 +1,86 @@
+/*
+ * kzg_mi355x.h -- C ABI of libkzg_mi355x.so, the MI355X (gfx950) engine behind the
+ * hot path of swusjask/kzg-snark:
+ *
+ *     fft_ff / ifft_ff / fft_ff_interpolation        (reference fft_ff.py:3,39,60)
+ *     KZG.commit / KZG.open                           (reference kzg.py:80,122)
+ *     KZG.setup's [tau^i G1] table                    (reference kzg.py:56-78)
+ *
+ * The reference has no FFI of its own (it is pure Python on SageMath + py_ecc);
+ * these entry points are what a ctypes binding placed inside those five
+ * functions calls (INTEGRATION.md shows the stubs).  Plain pointers and sizes
+ * only; no exceptions cross the boundary.
+ *
+ * Conventions
+ *  - Every function returns 0 on success or a negative KZG_ERR_* code;
+ *    kzg_last_error(ctx) gives the message of the last failure on that context.
+ *  - Field elements cross the boundary in CANONICAL form (integers < modulus,
+ *    not Montgomery), little-endian 64-bit limbs: 4 limbs (32 B) for the scalar
+ *    field Fr of either curve and for BN254's Fp, 6 limbs (48 B) for BLS12-381's
+ *    Fp.  Scalars and NTT data MUST be reduced (< r): the facade does
+ *    int(x) % r exactly like the reference's int(coeff) / Fq(x) coercions.
+ *  - G1 points cross as affine (x, y) = 2*FP_LIMBS limbs plus a separate
+ *    infinity flag byte (the reference's Z1, kzg.py:43).
+ *  - "host" entry points take host pointers, copy in/out and synchronise.
+ *    "_device" entry points take device pointers (>= 32-byte aligned), enqueue on
+ *    the context's stream and return without synchronising.
+ *  - A context is bound to one GPU and one stream; it is not thread-safe (one
+ *    context per thread).  The library owns all device memory behind handles.
+ *  - There is NO CPU fallback: without a gfx950 device kzg_ctx_create fails
+ *    with KZG_ERR_NODEV.
+ */
+#ifndef KZG_MI355X_H
+#define KZG_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZG_CURVE_BN254 0      /* reference default, kzg.py:18,26 */
+#define KZG_CURVE_BLS12_381 1  /* kzg.py:31 */
+
+#define KZG_OK 0
+#define KZG_ERR_ARG (-1)
+#define KZG_ERR_HIP (-2)
+#define KZG_ERR_NODEV (-3)
+#define KZG_ERR_DEGREE (-4) /* polynomial longer than the SRS: ValueError at kzg.py:103-106 */
+#define KZG_ERR_ALLOC (-5)
+
+typedef struct kzg_ctx kzg_ctx;
+typedef struct kzg_srs kzg_srs;
+
+/* ABI version of this header (bumped on incompatible change). */
+int kzg_abi_version(void);
+
+/* Limbs (uint64) per base-field element for a curve: 4 (BN254) or 6 (BLS12-381); 0 if unknown.
+ * Curve selection mirrors KZG.__init__ (kzg.py:26-37). */
+int kzg_fp_limbs(int curve_id);
+
+/* Create / destroy a context on HIP device `device_id`. */
+int kzg_ctx_create(int curve_id, int device_id, kzg_ctx** out);
+void kzg_ctx_destroy(kzg_ctx* ctx);
+const char* kzg_last_error(const kzg_ctx* ctx);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work of this context.
+ * NULL restores the context's own stream. */
+int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream);
+/* Block until everything enqueued on the context's stream has finished. */
+int kzg_ctx_synchronize(kzg_ctx* ctx);
+
+/* ---- NTT: replaces fft_ff (fft_ff.py:3-37) and ifft_ff (fft_ff.py:39-58) -------------
+ * data: n = 2^log_n elements of Fr, natural order in and out, transformed in place.
+ * w: the caller's root, exactly the `w` argument of fft_ff / ifft_ff.  The result is that
+ * of the reference recursion for any w (primitive or not).  inverse != 0 => ifft_ff:
+ * transform with w^-1, then scale by n^-1. */
+int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], int inverse);
+/* Same on `batch` consecutive device-resident arrays of n elements each. */
+int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                   uint32_t batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZG_MI355X_H */

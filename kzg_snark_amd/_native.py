@@ -1,0 +1,241 @@
+"""ctypes binding of libkzg_mi355x.so (include/kzg_mi355x.h).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device
+is visible, the first call raises NativeUnavailable -- loudly, by design."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkzg_mi355x.so")
+
+KZG_CURVE_BN254 = 0
+KZG_CURVE_BLS12_381 = 1
+CURVE_IDS = {"bn254": KZG_CURVE_BN254, "bls12_381": KZG_CURVE_BLS12_381}
+
+KZG_ERR_DEGREE = -4
+KZG_ERR_NODEV = -3
+
+# every symbol include/kzg_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+SIGNATURES = {
+    "kzg_abi_version": (ctypes.c_int, []),
+    "kzg_fp_limbs": (ctypes.c_int, [ctypes.c_int]),
+    "kzg_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    "kzg_ctx_destroy": (None, [_vp]),
+    "kzg_last_error": (ctypes.c_char_p, [_vp]),
+    "kzg_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "kzg_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "kzg_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int]),
+    "kzg_ntt_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint32]),
+    "kzg_srs_load_g1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "kzg_srs_free": (None, [_vp]),
+    "kzg_srs_size": (ctypes.c_size_t, [_vp]),
+    "kzg_srs_generate": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "kzg_srs_export": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "kzg_commit": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "kzg_commit_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "kzg_open": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "kzg_open_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class NativeUnavailable(RuntimeError):
+    pass
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libkzg_mi355x error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+MISSING = []
+
+
+def lib():
+    """Load the shared library (no GPU needed for loading; needed for contexts)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeUnavailable(
+                f"{LIB_PATH} not built: run `python -m kzg_snark_amd.build` (no CPU fallback exists)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is None:          # tests/test_abi.py requires MISSING to stay empty
+                MISSING.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _as_vp(a):
+    """numpy array / int device pointer / ctypes array -> c_void_p."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    return ctypes.cast(a, ctypes.c_void_p)
+
+
+class Context:
+    """One engine context: one curve, one GPU, one stream (kzg_ctx)."""
+
+    def __init__(self, curve_type="bls12_381", device=0):
+        if curve_type not in CURVE_IDS:
+            raise ValueError(f"Unsupported curve type: {curve_type}")    # kzg.py:37
+        self.curve_type = curve_type
+        self.curve_id = CURVE_IDS[curve_type]
+        self.fp_limbs = lib().kzg_fp_limbs(self.curve_id)
+        h = ctypes.c_void_p()
+        rc = lib().kzg_ctx_create(self.curve_id, int(device), ctypes.byref(h))
+        if rc == KZG_ERR_NODEV:
+            raise NativeUnavailable(
+                "kzg_ctx_create: no gfx950 (MI355X) device visible; this engine has no CPU fallback")
+        if rc != 0:
+            raise NativeError(rc, "kzg_ctx_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kzg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = lib().kzg_last_error(self._h)
+            raise NativeError(rc, msg.decode() if msg else "")
+
+    def set_stream(self, stream_ptr):
+        self._check(lib().kzg_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._check(lib().kzg_ctx_synchronize(self._h))
+
+    # ---- NTT
+    def ntt(self, data, log_n, w_words, inverse):
+        """data: C-contiguous uint64[n,4] numpy array, transformed in place."""
+        assert data.dtype == np.uint64 and data.flags.c_contiguous and data.size == 4 << log_n
+        self._check(lib().kzg_ntt(self._h, _as_vp(data), log_n, _as_vp(w_words), int(bool(inverse))))
+
+    def ntt_device(self, d_ptr, log_n, w_words, inverse, batch=1):
+        self._check(lib().kzg_ntt_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
+                                         int(bool(inverse)), batch))
+
+    # ---- SRS
+    def srs_load_g1(self, xy, inf=None):
+        """xy: uint64[n, 2*fp_limbs] affine canonical; inf: uint8[n] flags or None."""
+        n = xy.shape[0]
+        assert xy.dtype == np.uint64 and xy.flags.c_contiguous and xy.shape[1] == 2 * self.fp_limbs
+        if inf is not None:
+            assert inf.dtype == np.uint8 and inf.size == n and inf.flags.c_contiguous
+        h = ctypes.c_void_p()
+        self._check(lib().kzg_srs_load_g1(self._h, _as_vp(xy), _as_vp(inf), n, ctypes.byref(h)))
+        return Srs(self, h, n)
+
+    def srs_generate(self, tau_words, n):
+        h = ctypes.c_void_p()
+        self._check(lib().kzg_srs_generate(self._h, _as_vp(tau_words), n, ctypes.byref(h)))
+        return Srs(self, h, n)
+
+    # ---- commit / open on host buffers
+    def commit(self, srs, scalars, lens, stride):
+        """scalars: uint64[n_polys, stride, 4]; lens: per-polynomial coefficient counts."""
+        n_polys = len(lens)
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        out_xy = np.zeros((n_polys, 2 * self.fp_limbs), dtype=np.uint64)
+        out_inf = np.zeros(n_polys, dtype=np.uint8)
+        self._check(lib().kzg_commit(self._h, srs._h, _as_vp(scalars), _as_vp(lens_a), n_polys, stride,
+                                     _as_vp(out_xy), _as_vp(out_inf)))
+        return out_xy, out_inf
+
+    def commit_device(self, srs, d_scalars, lens, stride):
+        n_polys = len(lens)
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        out_xy = np.zeros((n_polys, 2 * self.fp_limbs), dtype=np.uint64)
+        out_inf = np.zeros(n_polys, dtype=np.uint8)
+        self._check(lib().kzg_commit_device(self._h, srs._h, _as_vp(d_scalars), _as_vp(lens_a), n_polys,
+                                            stride, _as_vp(out_xy), _as_vp(out_inf)))
+        return out_xy, out_inf
+
+    def open(self, srs, polys, lens, stride, z_words, xi_words, device=False):
+        k = len(lens)
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        out_xy = np.zeros(2 * self.fp_limbs, dtype=np.uint64)
+        out_inf = np.zeros(1, dtype=np.uint8)
+        ev = np.zeros(4, dtype=np.uint64)
+        fn = lib().kzg_open_device if device else lib().kzg_open
+        self._check(fn(self._h, srs._h, _as_vp(polys), _as_vp(lens_a), k, stride, _as_vp(z_words),
+                       _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf), _as_vp(ev)))
+        return out_xy, out_inf, ev
+
+
+class Srs:
+    """Device-resident commitment key (kzg_srs): the reference's `ck` list."""
+
+    def __init__(self, ctx, h, n):
+        self.ctx = ctx
+        self._h = h
+        self.n = n
+
+    def export(self, start=0, count=None):
+        count = self.n - start if count is None else count
+        xy = np.zeros((count, 2 * self.ctx.fp_limbs), dtype=np.uint64)
+        inf = np.zeros(count, dtype=np.uint8)
+        self.ctx._check(lib().kzg_srs_export(self.ctx._h, self._h, start, count, _as_vp(xy), _as_vp(inf)))
+        return xy, inf
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            lib().kzg_srs_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def get_context(curve_type, device=0):
+    key = (curve_type, device)
+    if key not in _contexts:
+        _contexts[key] = Context(curve_type, device)
+    return _contexts[key]
+
+
+# ---- integer <-> limb marshalling -------------------------------------------------
+
+def ints_to_limbs(values, limbs=4):
+    """list of non-negative ints (< 2^(64*limbs)) -> uint64[n, limbs] (little-endian)."""
+    nb = 8 * limbs
+    buf = b"".join(int(v).to_bytes(nb, "little") for v in values)
+    return np.frombuffer(buf, dtype="<u8").reshape(len(values), limbs).copy()
+
+
+def limbs_to_ints(arr):
+    a = np.ascontiguousarray(arr, dtype="<u8")
+    nb = 8 * a.shape[-1]
+    raw = a.tobytes()
+    return [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
+
+
+def int_to_words(v, limbs=4):
+    return np.frombuffer(int(v).to_bytes(8 * limbs, "little"), dtype="<u8").copy()

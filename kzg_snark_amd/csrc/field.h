@@ -1,0 +1,263 @@
+// field.h -- prime-field arithmetic for the KZG engine, shared by gfx950 device
+// code and the host side of the C-ABI library.
+//
+// Representation ("unsaturated limbs"): an element is N limbs of L bits held in
+// 32-bit words, value = sum l[j] * 2^(L*j).  L = 29 (N = 9) for the ~255-bit
+// fields, L = 28 (N = 14) for the 381-bit BLS12-381 base field.  The point of the
+// slack bits is the multiplier: on gfx950 a 32x32+64 multiply-add
+// (v_mad_u64_u32) issues at the same rate as an FP64 FMA (measured,
+// tools/microbench/int_rates.hip) but has no carry-in, so with saturated
+// 32-bit limbs every partial product needs extra carry instructions (hipcc's
+// CIOS for 12 limbs: 288 mads + 295 64-bit adds + 620 moves).  With L-bit limbs
+// a whole operand-scanning Montgomery product accumulates into 64-bit columns
+// without ever overflowing, so each partial product is exactly one
+// v_mad_u64_u32 and nothing else.
+//
+// Invariant of every value returned by this header ("weak-normal"): limbs
+// l[0..N-2] < 2^L, top limb small and non-negative, value in [0, 2p).
+// reduce() brings a value to the canonical range [0, p).
+//
+// Montgomery radix R = 2^(L*N); 4p < R for all four fields, so mul() maps
+// weak-normal inputs to a weak-normal output:  (ab + mp)/R < 4p^2/R + p < 2p.
+//
+// Bound for mul(): inputs may have limbs up to 2^30 (sums of unnormalised
+// values): a column receives at most N products a_j*b_i < 2^60 and N products
+// m*p_j < 2^(2L) plus a carry < 2^37, i.e. < 14*2^60 + 14*2^56 + 2^37 < 2^64.
+#pragma once
+#include <stdint.h>
+#include "curve_constants.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KZG_HD __host__ __device__ __forceinline__
+#else
+#define KZG_HD inline __attribute__((always_inline))
+#endif
+
+namespace kzg {
+
+template <class F>
+struct Fe {
+  uint32_t l[F::N];
+};
+
+template <class F>
+struct Field {
+  static constexpr int L = F::L;
+  static constexpr int N = F::N;
+  static constexpr int NW = F::NW;
+  static constexpr uint32_t MASK = F::MASK;
+  using E = Fe<F>;
+
+  static KZG_HD E zero() {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = 0;
+    return r;
+  }
+  // Montgomery form of 1
+  static KZG_HD E one() {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = F::R1[j];
+    return r;
+  }
+  // the plain integer 1 (mul(a, raw_one()) converts out of Montgomery form)
+  static KZG_HD E raw_one() {
+    E r = zero();
+    r.l[0] = 1;
+    return r;
+  }
+  static KZG_HD E r2() {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = F::R2[j];
+    return r;
+  }
+
+  // canonical saturated little-endian words (NW x 32 bit) -> limbs.  The value
+  // is taken as is (no reduction): callers pass values < p.
+  static KZG_HD E from_words(const uint32_t* w) {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int bit = j * L;
+      const int k = bit >> 5, sh = bit & 31;
+      uint64_t lo = (k < NW) ? w[k] : 0u;
+      uint64_t hi = (k + 1 < NW) ? w[k + 1] : 0u;
+      r.l[j] = (uint32_t)(((hi << 32) | lo) >> sh) & MASK;
+    }
+    return r;
+  }
+  // limbs -> canonical words.  Requires a canonical element (reduce() first).
+  static KZG_HD void to_words(const E& a, uint32_t* w) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      // word k covers bits [32k, 32k+32)
+      const int j0 = (32 * k) / L;           // first limb touching the word
+      const int off0 = 32 * k - j0 * L;      // bit offset inside limb j0
+      uint64_t acc = (uint64_t)a.l[j0] >> off0;
+      int have = L - off0;
+      if (j0 + 1 < N) {
+        acc |= (uint64_t)a.l[j0 + 1] << have;
+        have += L;
+      }
+      if (have < 32 && j0 + 2 < N) acc |= (uint64_t)a.l[j0 + 2] << have;
+      w[k] = (uint32_t)acc;
+    }
+  }
+
+  // Montgomery product a*b/R.  See the header comment for input bounds.
+  static KZG_HD E mul(const E& a, const E& b) {
+    uint64_t w[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) w[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t bi = b.l[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) w[j] += (uint64_t)a.l[j] * bi;
+      const uint32_t m = ((uint32_t)w[0] * F::N0) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; ++j) w[j] += (uint64_t)m * F::P[j];
+      // low L bits of w[0] are now zero: divide by 2^L and slide the window
+      const uint64_t c = w[0] >> L;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
+      w[N - 1] = 0;
+      w[0] += c;
+    }
+    E r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint64_t t = w[j] + c;
+      r.l[j] = (uint32_t)t & MASK;
+      c = t >> L;
+    }
+    r.l[N - 1] = (uint32_t)(w[N - 1] + c);
+    return r;
+  }
+  static KZG_HD E sqr(const E& a) { return mul(a, a); }
+
+  // a + b, weak-normal in and out
+  static KZG_HD E add(const E& a, const E& b) {
+    E s, t;
+    uint32_t cs = 0;
+    int32_t ct = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const uint32_t x = a.l[j] + b.l[j];
+      const uint32_t sj = x + cs;
+      const int32_t tj = (int32_t)(x - F::P2[j]) + ct;
+      if (j < N - 1) {
+        cs = sj >> L;
+        s.l[j] = sj & MASK;
+        ct = tj >> L;
+        t.l[j] = (uint32_t)tj & MASK;
+      } else {
+        s.l[j] = sj;
+        t.l[j] = (uint32_t)tj;
+      }
+    }
+    const bool neg = (int32_t)t.l[N - 1] < 0;
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = neg ? s.l[j] : t.l[j];
+    return r;
+  }
+  // a - b, weak-normal in and out
+  static KZG_HD E sub(const E& a, const E& b) {
+    E u, t;
+    int32_t cu = 0, ct = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int32_t x = (int32_t)a.l[j] - (int32_t)b.l[j];
+      const int32_t tj = x + ct;
+      const int32_t uj = x + (int32_t)F::P2[j] + cu;
+      if (j < N - 1) {
+        ct = tj >> L;
+        t.l[j] = (uint32_t)tj & MASK;
+        cu = uj >> L;
+        u.l[j] = (uint32_t)uj & MASK;
+      } else {
+        t.l[j] = (uint32_t)tj;
+        u.l[j] = (uint32_t)uj;
+      }
+    }
+    const bool neg = (int32_t)t.l[N - 1] < 0;
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = neg ? u.l[j] : t.l[j];
+    return r;
+  }
+  static KZG_HD E dbl(const E& a) { return add(a, a); }
+  static KZG_HD E neg(const E& a) { return sub(zero(), a); }
+
+  // [0, 2p) -> [0, p)
+  static KZG_HD E reduce(const E& a) {
+    E t;
+    int32_t ct = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int32_t tj = (int32_t)a.l[j] - (int32_t)F::P[j] + ct;
+      if (j < N - 1) {
+        ct = tj >> L;
+        t.l[j] = (uint32_t)tj & MASK;
+      } else {
+        t.l[j] = (uint32_t)tj;
+      }
+    }
+    const bool neg = (int32_t)t.l[N - 1] < 0;
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = neg ? a.l[j] : t.l[j];
+    return r;
+  }
+  static KZG_HD bool is_zero(const E& a) {
+    const E r = reduce(a);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc |= r.l[j];
+    return acc == 0;
+  }
+  static KZG_HD bool eq(const E& a, const E& b) { return is_zero(sub(a, b)); }
+
+  static KZG_HD E to_mont(const E& a) { return mul(a, r2()); }
+  static KZG_HD E from_mont(const E& a) { return reduce(mul(a, raw_one())); }
+
+  static KZG_HD E select(bool c, const E& a, const E& b) {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = c ? a.l[j] : b.l[j];
+    return r;
+  }
+
+  // a^e for a Montgomery-form a; e given as `nw` saturated 32-bit words.
+  // Not unrolled: used off the hot path (table construction, host finishing).
+  static KZG_HD E pow_words(const E& a, const uint32_t* e, int nw) {
+    E r = one();
+    for (int k = nw - 1; k >= 0; --k) {
+      for (int bit = 31; bit >= 0; --bit) {
+        r = mul(r, r);
+        if ((e[k] >> bit) & 1u) r = mul(r, a);
+      }
+    }
+    return r;
+  }
+  // a^(p-2) (Montgomery form in and out); inv(0) = 0
+  static KZG_HD E inv(const E& a) {
+    uint32_t e[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) e[k] = F::PW[k];
+    uint32_t borrow = 2;  // e = p - 2
+    for (int k = 0; k < NW && borrow; ++k) {
+      const uint32_t old = e[k];
+      e[k] = old - borrow;
+      borrow = old < borrow ? 1u : 0u;
+    }
+    return pow_words(a, e, NW);
+  }
+};
+
+}  // namespace kzg

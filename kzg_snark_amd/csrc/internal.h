@@ -1,0 +1,70 @@
+// internal.h -- library-private declarations shared by the translation units of
+// libkzg_mi355x.so (api.hip, ntt.hip, msm.hip, poly.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "field.h"
+
+namespace kzg {
+
+constexpr int KZG_OK = 0;
+constexpr int KZG_ERR_ARG = -1;      // bad argument
+constexpr int KZG_ERR_HIP = -2;      // HIP runtime error (see kzg_last_error)
+constexpr int KZG_ERR_NODEV = -3;    // no usable gfx950 device
+constexpr int KZG_ERR_DEGREE = -4;   // polynomial longer than the SRS (kzg.py:103-106)
+constexpr int KZG_ERR_ALLOC = -5;
+
+// A cached evaluation domain: everything the NTT kernels need for one
+// (log_n, w, direction).  Built once per distinct root (callers reuse the same
+// domain for every transform of a proof: plonk/encoder.py:49).
+struct NttDomain {
+  uint32_t log_n = 0;
+  int inverse = 0;
+  uint32_t w[8] = {0};        // caller's root, canonical words
+  uint32_t kmax = 0;          // stage table holds (w^(n/2^kmax))^e, e < 2^(kmax-1)
+  uint32_t h = 0;             // twist exponent split e = hi*2^h + lo
+  uint32_t* d_stage = nullptr;   // [2^(kmax-1)][9] Montgomery limbs
+  uint32_t* d_twA = nullptr;     // [2^(log_n-h)][9]  (w^(2^h))^u  (x n^-1 when inverse)
+  uint32_t* d_twB = nullptr;     // [2^h][9]          w^l
+  uint32_t* d_scale = nullptr;   // [9] n^-1 in Montgomery form (inverse, single-pass sizes)
+  uint64_t last_use = 0;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct Ctx {
+  int curve = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::vector<NttDomain> domains;
+  uint64_t tick = 0;
+  DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
+  DevBuf io;              // staging for the host-pointer entry points
+  DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
+  std::vector<hipStream_t> aux_streams;   // commit pipeline
+  std::vector<hipEvent_t> aux_events;
+};
+
+int set_err(Ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+int ensure_buf(Ctx* c, DevBuf& b, size_t bytes);
+
+#define KZG_HIP(c, call)                                         \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) return set_err((c), KZG_ERR_HIP, #call, e__); \
+  } while (0)
+
+// ntt.hip
+int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse,
+                   uint32_t batch);
+void ntt_free_domains(Ctx* c);
+
+}  // namespace kzg

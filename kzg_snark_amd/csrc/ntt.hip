@@ -1,0 +1,309 @@
+// ntt.hip -- radix-2 NTT / INTT over the scalar field Fr on gfx950.
+//
+// Replaces the recursion of the reference's fft_ff (fft_ff.py:3-37) and the
+// w^-1 / n^-1 wrapper ifft_ff (fft_ff.py:39-58).  Semantics are those of the
+// recursion, for ANY w (primitive or not): at the level that merges two halves
+// of length m/2 the butterfly i uses the twiddle (w^(n/m))^i,
+//     out[i] = E[i] + tw*O[i],   out[i + m/2] = E[i] - tw*O[i]     (fft_ff.py:32-35)
+// which the iterative decimation-in-time form (bit-reversed placement, stages
+// m = 2, 4, .., n) reproduces operation for operation.
+//
+// Decomposition (n = N1*N2, x viewed as an N1 x N2 row-major matrix):
+//   pass 1: N1-point transforms down the columns (root w^N2), then element
+//           (t, v) is multiplied by w^(t*v);
+//   pass 2: N2-point transforms along the rows (root w^N1); row t, output
+//           index b lands at out[b*N1 + t].
+// The twist w^(t*v) is an exact field identity for every w (the t-dependent
+// factor of every later-stage twiddle only depends on the input position), so
+// the result equals the recursion's for non-primitive w as well.
+//
+// Each workgroup owns one LDS tile of up to 4096 elements (C lines of 2^k
+// elements; 36 B per element: 9 limbs of 29 bits, stride 9 words => conflict-free
+// ds_read_b32/ds_write_b32 across consecutive lanes).  All k stages of the tile
+// run out of LDS with one barrier per stage; HBM is touched once for the load
+// and once for the store of each pass.  Data stays in standard (non-Montgomery)
+// form: twiddles are kept in Montgomery form, so mont_mul(x, tw*R) = x*tw.
+#include "internal.h"
+#include <algorithm>
+#include <cstring>
+
+namespace kzg {
+
+namespace {
+
+constexpr int TILE_LOG = 12;            // elements per LDS tile (4096 * 36 B = 144 KiB)
+constexpr int FRN = 9;                  // limbs of both scalar fields
+
+struct NttPassArgs {
+  const uint32_t* src;
+  uint32_t* dst;
+  const uint32_t* stage;   // stage twiddles (Montgomery), root order 2^kmax
+  const uint32_t* twA;     // twist tables or nullptr
+  const uint32_t* twB;
+  const uint32_t* scale;   // optional final scale (Montgomery) or nullptr
+  uint32_t k;              // log2 line length
+  uint32_t logC;           // log2 lines per tile
+  uint32_t kmax;
+  uint32_t h;              // twist split
+  uint32_t c_fast_load;    // consecutive threads walk lines first when loading
+  uint64_t ld_line, ld_pos, tile_ld;
+  uint64_t st_line, st_pos, tile_st;
+  uint64_t batch_stride;   // elements between transforms of a batch (blockIdx.y)
+};
+
+// LDS word address of element `pos` of line `line`.  Elements are 9 words; one
+// pad word per 32 elements makes the bit-reversed scatter of the load phase
+// (positions c + u*LEN/32) hit 32 different banks, and a one-word skew per line
+// separates the lines of a tile (whose 9*LEN-word stride is a multiple of 32).
+__device__ __forceinline__ uint32_t lds_addr(uint32_t line, uint32_t k, uint32_t pos) {
+  const uint32_t e = (line << k) + pos;
+  return e * FRN + (e >> 5) + line;
+}
+template <class F>
+__device__ __forceinline__ Fe<F> lds_get(const uint32_t* lds, uint32_t addr) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) r.l[j] = lds[addr + j];
+  return r;
+}
+template <class F>
+__device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t addr, const Fe<F>& v) {
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) lds[addr + j] = v.l[j];
+}
+template <class F>
+__device__ __forceinline__ Fe<F> glb_get_limbs(const uint32_t* p) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) r.l[j] = p[j];
+  return r;
+}
+
+template <class F>
+__global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
+  using Fd = Field<F>;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  const uint32_t k = a.k, logC = a.logC;
+  const uint32_t LEN = 1u << k, C = 1u << logC, TILE = LEN << logC;
+  const uint64_t tile = blockIdx.x;
+  const uint32_t* src = a.src + (a.batch_stride * blockIdx.y + tile * a.tile_ld) * 8;
+  uint32_t* dst = a.dst + (a.batch_stride * blockIdx.y + tile * a.tile_st) * 8;
+
+  // ---- load: canonical words -> limbs, bit-reversed placement inside each line
+  for (uint32_t idx = tid; idx < TILE; idx += T) {
+    uint32_t line, pos;
+    if (a.c_fast_load) { line = idx & (C - 1); pos = idx >> logC; }
+    else               { pos = idx & (LEN - 1); line = idx >> k; }
+    const uint4* g = reinterpret_cast<const uint4*>(src + (line * a.ld_line + pos * a.ld_pos) * 8);
+    const uint4 lo = g[0], hi = g[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const uint32_t rpos = k ? (__brev(pos) >> (32 - k)) : 0u;
+    lds_put<F>(lds, lds_addr(line, k, rpos), Fd::from_words(w));
+  }
+  __syncthreads();
+
+  // ---- k butterfly stages in LDS
+  for (uint32_t s = 1; s <= k; ++s) {
+    const uint32_t half = 1u << (s - 1);
+    for (uint32_t bf = tid; bf < TILE / 2; bf += T) {
+      const uint32_t line = bf >> (k - 1);
+      const uint32_t rem = bf & (LEN / 2 - 1);
+      const uint32_t i = rem & (half - 1);
+      const uint32_t blk = rem >> (s - 1);
+      const uint32_t p0 = lds_addr(line, k, (blk << s) + i);
+      const uint32_t p1 = lds_addr(line, k, (blk << s) + i + half);
+      const Fe<F> x = lds_get<F>(lds, p0);
+      Fe<F> y = lds_get<F>(lds, p1);
+      if (s > 1) {  // stage 1 has the single twiddle w^0 = 1 (wave-uniform test)
+        const Fe<F> tw = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s)) * F::N);
+        y = Fd::mul(y, tw);
+      }
+      lds_put<F>(lds, p0, Fd::add(x, y));
+      lds_put<F>(lds, p1, Fd::sub(x, y));
+    }
+    __syncthreads();
+  }
+
+  // ---- store: optional twist w^(pos*col), optional scale, canonical words out
+  for (uint32_t idx = tid; idx < TILE; idx += T) {
+    const uint32_t line = idx & (C - 1), pos = idx >> logC;
+    Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
+    if (a.twA) {
+      const uint64_t col = tile * C + line;
+      const uint64_t e = (uint64_t)pos * col;
+      const Fe<F> ta = glb_get_limbs<F>(a.twA + (size_t)(e >> a.h) * F::N);
+      const Fe<F> tb = glb_get_limbs<F>(a.twB + (size_t)(e & ((1ull << a.h) - 1)) * F::N);
+      x = Fd::mul(x, Fd::mul(ta, tb));
+    }
+    if (a.scale) x = Fd::mul(x, glb_get_limbs<F>(a.scale));
+    x = Fd::reduce(x);
+    uint32_t w[8];
+    Fd::to_words(x, w);
+    uint4* g = reinterpret_cast<uint4*>(dst + (line * a.st_line + pos * a.st_pos) * 8);
+    g[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
+// out[e] = mult * base^e  (all Montgomery form), e < count
+template <class F>
+__global__ void pow_table_kernel(uint32_t* out, const uint32_t* base_mult, uint32_t count) {
+  using Fd = Field<F>;
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  Fe<F> b = glb_get_limbs<F>(base_mult);
+  Fe<F> acc = glb_get_limbs<F>(base_mult + F::N);
+  for (uint32_t bits = e; bits; bits >>= 1) {
+    if (bits & 1u) acc = Fd::mul(acc, b);
+    b = Fd::mul(b, b);
+  }
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) out[(size_t)e * F::N + j] = acc.l[j];
+}
+
+template <class F>
+int build_domain(Ctx* c, NttDomain& d) {
+  using Fd = Field<F>;
+  const uint32_t log_n = d.log_n;
+  Fe<F> w = Fd::to_mont(Fd::from_words(d.w));
+  if (d.inverse) w = Fd::inv(w);                       // fft_ff.py:53
+  // n^-1 (fft_ff.py:57): n as a field element, inverted
+  uint32_t nw[8] = {0};
+  nw[log_n >> 5] = 1u << (log_n & 31);
+  const Fe<F> ninv = Fd::inv(Fd::to_mont(Fd::from_words(nw)));
+
+  const bool two_pass = log_n > (uint32_t)TILE_LOG;
+  d.kmax = two_pass ? (log_n + 1) / 2 : log_n;
+  d.h = (log_n + 1) / 2;
+  auto pow2k = [&](Fe<F> x, uint32_t sq) { for (uint32_t i = 0; i < sq; ++i) x = Fd::mul(x, x); return x; };
+
+  struct Job { uint32_t** dst; Fe<F> base; Fe<F> mult; uint32_t count; };
+  std::vector<Job> jobs;
+  if (d.kmax >= 1) jobs.push_back({&d.d_stage, pow2k(w, log_n - d.kmax), Fd::one(), 1u << (d.kmax - 1)});
+  if (two_pass) {
+    jobs.push_back({&d.d_twA, pow2k(w, d.h), d.inverse ? ninv : Fd::one(), 1u << (log_n - d.h)});
+    jobs.push_back({&d.d_twB, w, Fd::one(), 1u << d.h});
+  }
+  uint32_t* d_tmp = nullptr;
+  KZG_HIP(c, hipMalloc(&d_tmp, 2 * F::N * 4));
+  for (auto& j : jobs) {
+    KZG_HIP(c, hipMalloc(j.dst, (size_t)j.count * F::N * 4));
+    uint32_t hb[2 * F::N];
+    memcpy(hb, j.base.l, F::N * 4);
+    memcpy(hb + F::N, j.mult.l, F::N * 4);
+    KZG_HIP(c, hipMemcpyAsync(d_tmp, hb, sizeof(hb), hipMemcpyHostToDevice, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));   // hb is a stack buffer
+    hipLaunchKernelGGL(pow_table_kernel<F>, dim3((j.count + 255) / 256), dim3(256), 0, c->stream, *j.dst,
+                       d_tmp, j.count);
+    KZG_HIP(c, hipGetLastError());
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  KZG_HIP(c, hipFree(d_tmp));
+  if (d.inverse && !two_pass) {
+    KZG_HIP(c, hipMalloc(&d.d_scale, F::N * 4));
+    KZG_HIP(c, hipMemcpy(d.d_scale, ninv.l, F::N * 4, hipMemcpyHostToDevice));
+  }
+  return KZG_OK;
+}
+
+template <class F>
+int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) {
+  const uint32_t log_n = d.log_n;
+  const uint64_t n = 1ull << log_n;
+  auto launch = [&](const NttPassArgs& a, uint64_t tiles) -> int {
+    const uint32_t tile_elems = 1u << (a.k + a.logC);
+    const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2));
+    const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
+    static bool lds_attr_set = false;   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+    if (!lds_attr_set) {
+      KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
+    KZG_HIP(c, hipGetLastError());
+    return KZG_OK;
+  };
+  if (log_n <= (uint32_t)TILE_LOG) {
+    NttPassArgs a{};
+    a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twA = nullptr; a.twB = nullptr;
+    a.scale = d.d_scale; a.k = log_n; a.logC = 0; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
+    a.ld_line = 0; a.ld_pos = 1; a.tile_ld = 0; a.st_line = 0; a.st_pos = 1; a.tile_st = 0;
+    a.batch_stride = n;
+    return launch(a, 1);
+  }
+  const uint32_t k1 = (log_n + 1) / 2, k2 = log_n - k1;
+  const uint64_t N1 = 1ull << k1, N2 = 1ull << k2;
+  int rc = ensure_buf(c, c->ntt_scratch, (size_t)n * batch * 32);
+  if (rc) return rc;
+  uint32_t* scratch = static_cast<uint32_t*>(c->ntt_scratch.p);
+  {  // pass 1: columns of the N1 x N2 matrix, twist by w^(t*v)
+    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, k2);
+    NttPassArgs a{};
+    a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twA = d.d_twA; a.twB = d.d_twB; a.scale = nullptr;
+    a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1;
+    a.ld_line = 1; a.ld_pos = N2; a.tile_ld = 1ull << logC;
+    a.st_line = 1; a.st_pos = N2; a.tile_st = 1ull << logC;
+    a.batch_stride = n;
+    rc = launch(a, N2 >> logC);
+    if (rc) return rc;
+  }
+  {  // pass 2: rows; row t, output index b -> out[b*N1 + t]
+    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k2, k1);
+    NttPassArgs a{};
+    a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twA = nullptr; a.twB = nullptr; a.scale = nullptr;
+    a.k = k2; a.logC = logC; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
+    a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
+    a.st_line = 1; a.st_pos = N1; a.tile_st = 1ull << logC;
+    a.batch_stride = n;
+    rc = launch(a, N1 >> logC);
+    if (rc) return rc;
+  }
+  return KZG_OK;
+}
+
+template <class F>
+int ntt_run_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, uint32_t batch) {
+  if (log_n == 0 || batch == 0) return KZG_OK;   // n == 1: fft_ff.py:16-17 returns the input; 1^-1 = 1
+  NttDomain* dom = nullptr;
+  for (auto& d : c->domains)
+    if (d.log_n == log_n && d.inverse == inverse && memcmp(d.w, w_words, 32) == 0) { dom = &d; break; }
+  if (!dom) {
+    if (c->domains.size() >= 16) {   // evict least recently used
+      size_t victim = 0;
+      for (size_t i = 1; i < c->domains.size(); ++i)
+        if (c->domains[i].last_use < c->domains[victim].last_use) victim = i;
+      NttDomain& v = c->domains[victim];
+      hipStreamSynchronize(c->stream);
+      hipFree(v.d_stage); hipFree(v.d_twA); hipFree(v.d_twB); hipFree(v.d_scale);
+      c->domains.erase(c->domains.begin() + victim);
+    }
+    NttDomain d;
+    d.log_n = log_n; d.inverse = inverse;
+    memcpy(d.w, w_words, 32);
+    int rc = build_domain<F>(c, d);
+    if (rc) return rc;
+    c->domains.push_back(d);
+    dom = &c->domains.back();
+  }
+  dom->last_use = ++c->tick;
+  return launch_passes<F>(c, *dom, d_data, batch);
+}
+
+}  // namespace
+
+int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, uint32_t batch) {
+  if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");
+  if (c->curve == 0) return ntt_run_t<BnFr>(c, d_data, log_n, w_words, inverse, batch);
+  return ntt_run_t<BlsFr>(c, d_data, log_n, w_words, inverse, batch);
+}
+
+void ntt_free_domains(Ctx* c) {
+  for (auto& d : c->domains) {
+    hipFree(d.d_stage); hipFree(d.d_twA); hipFree(d.d_twB); hipFree(d.d_scale);
+  }
+  c->domains.clear();
+}
+
+}  // namespace kzg

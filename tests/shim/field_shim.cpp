@@ -1,0 +1,47 @@
+// Host-only test shim: exposes kzg_snark_amd/csrc/field.h (the same header the
+// gfx950 kernels use) through a tiny C interface so tests/test_field_host.py can
+// check it against Python integers without a GPU.  Test infrastructure only.
+#include "../../kzg_snark_amd/csrc/field.h"
+using namespace kzg;
+
+template <class F>
+static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  using Fd = Field<F>;
+  auto A = Fd::to_mont(Fd::from_words(a));
+  auto B = Fd::to_mont(Fd::from_words(b));
+  typename Fd::E R;
+  switch (which) {
+    case 0: R = Fd::mul(A, B); break;
+    case 1: R = Fd::add(A, B); break;
+    case 2: R = Fd::sub(A, B); break;
+    case 3: R = Fd::inv(A); break;
+    case 4: R = Fd::neg(A); break;
+    case 5: R = Fd::dbl(A); break;
+    case 6: {  // chain: ((a+b)*(a-b) + a) * b - mixes weak-normal values
+      auto s = Fd::add(A, B), d = Fd::sub(A, B);
+      R = Fd::sub(Fd::mul(Fd::add(Fd::mul(s, d), A), B), Fd::neg(B));
+      break;
+    }
+    default: R = Fd::zero();
+  }
+  Fd::to_words(Fd::from_mont(R), out);
+}
+
+extern "C" int shim_field_op(int field, int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  switch (field) {
+    case 0: op<BnFr>(which, a, b, out); return 0;
+    case 1: op<BnFp>(which, a, b, out); return 0;
+    case 2: op<BlsFr>(which, a, b, out); return 0;
+    case 3: op<BlsFp>(which, a, b, out); return 0;
+  }
+  return -1;
+}
+extern "C" int shim_is_zero(int field, const uint32_t* a) {
+  switch (field) {
+    case 0: return Field<BnFr>::is_zero(Field<BnFr>::from_words(a));
+    case 1: return Field<BnFp>::is_zero(Field<BnFp>::from_words(a));
+    case 2: return Field<BlsFr>::is_zero(Field<BlsFr>::from_words(a));
+    case 3: return Field<BlsFp>::is_zero(Field<BlsFp>::from_words(a));
+  }
+  return -1;
+}

@@ -1,0 +1,140 @@
+"""GPU parity of the NTT path (csrc/ntt.hip through the C ABI and the fft_ff
+facade) against the oracle's restatement of fft_ff.py.  Bit-exact: integer work."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import py_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bls12_381", "bn254"]
+
+
+def _rand(r, n, rng):
+    return [rng.randrange(r) for _ in range(n)]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 6, 7, 10, 12, 13, 14])
+def test_forward_matches_oracle(native, curve, log_n):
+    cv = O.curve(curve)
+    rng = random.Random(1000 + log_n)
+    n = 1 << log_n
+    w = cv.root_of_unity(n)
+    x = _rand(cv.r, n, rng)
+    x[0] = cv.r - 1
+    if n > 2:
+        x[1] = 0
+    data = native.ints_to_limbs(x)
+    native.get_context(curve).ntt(data, log_n, native.int_to_words(w), False)
+    assert native.limbs_to_ints(data) == O.fft_ff(x, w, cv.r)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("log_n", [1, 3, 8, 12, 13])
+def test_inverse_matches_oracle(native, curve, log_n):
+    cv = O.curve(curve)
+    rng = random.Random(2000 + log_n)
+    n = 1 << log_n
+    w = cv.root_of_unity(n)
+    x = _rand(cv.r, n, rng)
+    data = native.ints_to_limbs(x)
+    native.get_context(curve).ntt(data, log_n, native.int_to_words(w), True)
+    assert native.limbs_to_ints(data) == O.ifft_ff(x, w, cv.r)
+
+
+@pytest.mark.parametrize("log_n", [2, 5, 12, 13])
+def test_non_primitive_w_follows_the_recursion(native, log_n):
+    """fft_ff never checks w (fft_ff.py:3-37): for a w that is not a primitive n-th
+    root the reference returns what its recursion computes, and so must we."""
+    cv = O.BLS12_381
+    rng = random.Random(3000 + log_n)
+    n = 1 << log_n
+    x = _rand(cv.r, n, rng)
+    for w in (rng.randrange(2, cv.r), 1, cv.root_of_unity(2 * n), 0):
+        data = native.ints_to_limbs(x)
+        native.get_context("bls12_381").ntt(data, log_n, native.int_to_words(w), False)
+        assert native.limbs_to_ints(data) == O.fft_ff(x, w, cv.r), f"w={w}"
+
+
+def test_edge_values(native):
+    cv = O.BLS12_381
+    n, log_n = 64, 6
+    w = cv.root_of_unity(n)
+    ctx = native.get_context("bls12_381")
+    for x in ([0] * n, [cv.r - 1] * n, [1] + [0] * (n - 1), [0] * (n - 1) + [cv.r - 1]):
+        data = native.ints_to_limbs(x)
+        ctx.ntt(data, log_n, native.int_to_words(w), False)
+        assert native.limbs_to_ints(data) == O.fft_ff(x, w, cv.r)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_full_size_2_20_properties(native, curve):
+    """BASELINE config 2: degree-2^20 NTT/INTT.  The Python oracle is too slow at
+    this size, so parity is carried by (a) round trip INTT(NTT(x)) == x,
+    (b) linearity on a second vector, (c) X[0] = sum x, X[n/2] = alternating sum,
+    (d) a strided spot check of 16 outputs against the DFT definition."""
+    cv = O.curve(curve)
+    r = cv.r
+    log_n = 20
+    n = 1 << log_n
+    w = cv.root_of_unity(n)
+    rs = np.random.RandomState(7)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(3)        # < 2^253 < r for both curves
+    x = native.limbs_to_ints(raw)
+    ctx = native.get_context(curve)
+    ww = native.int_to_words(w)
+    X = raw.copy()
+    ctx.ntt(X, log_n, ww, False)
+    Xi = native.limbs_to_ints(X)
+    assert Xi[0] == sum(x) % r
+    assert Xi[n // 2] == (sum(x[0::2]) - sum(x[1::2])) % r
+    for k in (1, 2, 3, 1023, 1024, 1025, n - 1, 777777):
+        wk = pow(w, k, r)
+        acc, p = 0, 1
+        for v in x:
+            acc += v * p
+            p = p * wk % r
+        assert Xi[k] == acc % r, k
+    back = X.copy()
+    ctx.ntt(back, log_n, ww, True)
+    assert np.array_equal(back, raw)
+    # linearity: NTT(x + 3y) == NTT(x) + 3 NTT(y)
+    y = [(v * 5 + 11) % r for v in x[:n]]
+    Y = native.ints_to_limbs(y)
+    ctx.ntt(Y, log_n, ww, False)
+    Yi = native.limbs_to_ints(Y)
+    z = [(a + 3 * b) % r for a, b in zip(x, y)]
+    Z = native.ints_to_limbs(z)
+    ctx.ntt(Z, log_n, ww, False)
+    Zi = native.limbs_to_ints(Z)
+    assert all(Zi[i] == (Xi[i] + 3 * Yi[i]) % r for i in range(0, n, 97))
+
+
+def test_facade_signatures(native):
+    """fft_ff / ifft_ff / fft_ff_interpolation keep the reference's call shapes."""
+    from kzg_snark_amd.fft_ff import fft_ff, ifft_ff, fft_ff_interpolation
+    from kzg_snark_amd.field import GF
+    cv = O.BLS12_381
+    F = GF(cv.r)
+    g = F.root_of_unity(16)
+    assert int(g) == cv.root_of_unity(16)
+    vals = [F(i * i + 1) for i in range(16)]
+    ev = fft_ff(vals, g, F)
+    assert [int(v) for v in ev] == O.fft_ff([int(v) for v in vals], int(g), cv.r)
+    co = ifft_ff(ev, g, F)
+    assert co == vals
+    single = [F(5)]
+    assert fft_ff(single, g, F) is single          # fft_ff.py:16-17
+    poly = fft_ff_interpolation([F(3)] * 16, g, F)
+    assert poly.degree() == 0 and poly.list() == [F(3)]   # trailing zeros dropped (fft_ff.py:85)
+    for i in range(16):
+        p2 = fft_ff_interpolation(vals, g, F)
+        assert p2(g ** i) == vals[i]
+    with pytest.raises(AssertionError):
+        fft_ff_interpolation(vals[:12], g, F)              # fft_ff.py:74
+    with pytest.raises(AssertionError):
+        fft_ff_interpolation(vals, F.root_of_unity(8), F)  # fft_ff.py:78

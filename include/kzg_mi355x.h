@@ -80,6 +80,42 @@ int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], i
 int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                    uint32_t batch);
 
+/* ---- commitment key: the `ck` list of KZG.setup / KZG.commit (kzg.py:56-78, 80) ------
+ * kzg_srs_load_g1 uploads n affine G1 points (xy: n x 2*FP_LIMBS limbs; inf: n flag bytes or
+ * NULL) and expands them into the engine's device table (msm.hip).  Points are checked to be
+ * on the curve (KZG_ERR_ARG otherwise).  The handle replaces passing `ck` on every call. */
+int kzg_srs_load_g1(kzg_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t n, kzg_srs** out);
+/* kzg_srs_generate builds [tau^i * G1], i = 0..n-1, on the device: the G1 half of KZG.setup
+ * (kzg.py:70-72) with the secret supplied by the caller (the reference samples it at :67). */
+int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** out);
+/* Read points [start, start+count) back as canonical affine coordinates. */
+int kzg_srs_export(kzg_ctx* ctx, const kzg_srs* srs, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
+size_t kzg_srs_size(const kzg_srs* srs);
+void kzg_srs_free(kzg_srs* srs);
+
+/* ---- KZG.commit (kzg.py:80-120) --------------------------------------------------------
+ * n_polys coefficient arrays, `stride` elements apart, polynomial p having lens[p] coefficients
+ * (low to high).  One affine point per polynomial: out_xy[p] (2*FP_LIMBS limbs), out_inf[p] = 1
+ * for the point at infinity (zero polynomial, kzg.py:109).  lens[p] > kzg_srs_size(srs) returns
+ * KZG_ERR_DEGREE -- the ValueError of kzg.py:103-106.  Zero coefficients contribute nothing
+ * (kzg.py:113-114). */
+int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const size_t* lens, size_t n_polys,
+               size_t stride, uint64_t* out_xy, uint8_t* out_inf);
+/* Same with device-resident scalars; results are still written to host memory (one point per
+ * polynomial), so the call synchronises the stream. */
+int kzg_commit_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, const size_t* lens, size_t n_polys,
+                      size_t stride, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ---- KZG.open (kzg.py:122-159) -----------------------------------------------------------
+ * combined = sum_i xi^(i+1) * polys[i]  (first polynomial scaled by xi, kzg.py:148-150);
+ * witness = (combined - combined(z)) // (X - z); the proof is commit(witness).
+ * eval_out (optional, 4 limbs) receives combined(z). */
+int kzg_open(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* polys, const size_t* lens, size_t k, size_t stride,
+             const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out);
+int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const size_t* lens, size_t k,
+                    size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
+                    uint64_t* eval_out);
+
 #ifdef __cplusplus
 }
 #endif

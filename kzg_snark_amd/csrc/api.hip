@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" surface of libkzg_mi355x.so (include/kzg_mi355x.h).
 #include "internal.h"
+#include "msm.h"
 #include "../../include/kzg_mi355x.h"
 #include <cstdio>
 #include <cstring>
@@ -8,6 +9,13 @@
 struct kzg_ctx {
   kzg::Ctx c;
 };
+struct kzg_srs {
+  kzg::Srs* s;
+};
+
+namespace kzg {
+int device_any_nonzero(Ctx* c, const uint32_t* d_words, size_t from, size_t to, bool* out);   // poly.hip
+}
 
 namespace kzg {
 
@@ -80,6 +88,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   ntt_free_domains(c);
+  msm_free_work(c);
   hipFree(c->ntt_scratch.p);
   hipFree(c->io.p);
   for (auto& b : c->poly_tmp) hipFree(b.p);
@@ -140,6 +149,104 @@ int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], i
   KZG_HIP(c, hipMemcpyAsync(data, c->io.p, bytes, hipMemcpyDeviceToHost, c->stream));
   KZG_HIP(c, hipStreamSynchronize(c->stream));
   return KZG_OK;
+}
+
+int kzg_srs_load_g1(kzg_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t n, kzg_srs** out) {
+  if (!ctx || !xy || !out) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  *out = nullptr;
+  KZG_HIP(c, hipSetDevice(c->device));
+  Srs* s = nullptr;
+  int rc = srs_load(c, xy, inf, n, &s);
+  if (rc) return rc;
+  *out = new kzg_srs{s};
+  return KZG_OK;
+}
+
+int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** out) {
+  if (!ctx || !tau || !out) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  *out = nullptr;
+  KZG_HIP(c, hipSetDevice(c->device));
+  Srs* s = nullptr;
+  int rc = srs_generate(c, tau, n, &s);
+  if (rc) return rc;
+  *out = new kzg_srs{s};
+  return KZG_OK;
+}
+
+int kzg_srs_export(kzg_ctx* ctx, const kzg_srs* srs, size_t start, size_t count, uint64_t* xy, uint8_t* inf) {
+  if (!ctx || !srs || !xy || !inf) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return srs_export(c, srs->s, start, count, xy, inf);
+}
+
+size_t kzg_srs_size(const kzg_srs* srs) { return srs ? srs->s->n : 0; }
+
+void kzg_srs_free(kzg_srs* srs) {
+  if (!srs) return;
+  srs_free(srs->s);
+  delete srs;
+}
+
+int kzg_commit_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, const size_t* lens, size_t n_polys,
+                      size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !srs || !lens || !out_xy || !out_inf || (n_polys && !d_scalars)) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return commit_device(c, srs->s, static_cast<const uint32_t*>(d_scalars), lens, n_polys, stride, out_xy, out_inf);
+}
+
+int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const size_t* lens, size_t n_polys,
+               size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !srs || !lens || !out_xy || !out_inf || (n_polys && stride && !scalars)) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = n_polys * stride * 32;
+  int rc = ensure_buf(c, c->io, bytes ? bytes : 32);
+  if (rc) return rc;
+  if (bytes) KZG_HIP(c, hipMemcpyAsync(c->io.p, scalars, bytes, hipMemcpyHostToDevice, c->stream));
+  return commit_device(c, srs->s, static_cast<const uint32_t*>(c->io.p), lens, n_polys, stride, out_xy, out_inf);
+}
+
+int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const size_t* lens, size_t k,
+                    size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
+                    uint64_t* eval_out) {
+  if (!ctx || !srs || !z || !xi || !out_xy || !out_inf || (k && (!lens || !d_polys))) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  uint32_t* d_quot = nullptr;
+  size_t qlen = 0;
+  uint64_t ev[4];
+  int rc = open_quotient_device(c, static_cast<const uint32_t*>(d_polys), lens, k, stride,
+                                reinterpret_cast<const uint32_t*>(z), reinterpret_cast<const uint32_t*>(xi), &d_quot,
+                                &qlen, ev);
+  if (rc) return rc;
+  if (eval_out) memcpy(eval_out, ev, 32);
+  const size_t srs_n = srs->s->n;
+  if (qlen > srs_n) {
+    // The reference checks the DEGREE of the witness (kzg.py:103 via :157): coefficients
+    // beyond the key are fine as long as they are zero.
+    bool nz = false;
+    rc = device_any_nonzero(c, d_quot, srs_n, qlen, &nz);
+    if (rc) return rc;
+    if (nz) return set_err(c, KZG_ERR_DEGREE, "witness polynomial longer than the commitment key");
+    qlen = srs_n;
+  }
+  return commit_device(c, srs->s, d_quot, &qlen, 1, qlen ? qlen : 1, out_xy, out_inf);
+}
+
+int kzg_open(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* polys, const size_t* lens, size_t k, size_t stride,
+             const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out) {
+  if (!ctx || !srs || !z || !xi || !out_xy || !out_inf || (k && (!lens || !polys))) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = k * stride * 32;
+  int rc = ensure_buf(c, c->io, bytes ? bytes : 32);
+  if (rc) return rc;
+  if (bytes) KZG_HIP(c, hipMemcpyAsync(c->io.p, polys, bytes, hipMemcpyHostToDevice, c->stream));
+  return kzg_open_device(ctx, srs, c->io.p, lens, k, stride, z, xi, out_xy, out_inf, eval_out);
 }
 
 }  // extern "C"

@@ -49,6 +49,7 @@ struct Ctx {
   DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
   DevBuf io;              // staging for the host-pointer entry points
   DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
+  void* msm_work = nullptr;               // MsmWork (msm.hip)
   std::vector<hipStream_t> aux_streams;   // commit pipeline
   std::vector<hipEvent_t> aux_events;
 };

@@ -1,0 +1,31 @@
+// msm.h -- library-private interface of msm.hip (SRS tables and the commit pipeline).
+#pragma once
+#include "internal.h"
+
+namespace kzg {
+
+// Device-resident commitment key: the reference's `ck` = [tau^i G1] (kzg.py:70-72),
+// expanded to NWIN window multiples per point (layout: msm.hip header comment).
+struct Srs {
+  size_t n = 0;
+  int curve = 0;
+  uint32_t* recs = nullptr;   // [NWIN][n] records of Curve::REC_WORDS words
+};
+
+int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out);
+int srs_generate(Ctx* c, const uint64_t* tau, size_t n, Srs** out);
+int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
+void srs_free(Srs* s);
+
+// One MSM per polynomial; scalars device-resident, results to host memory (synchronises).
+int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
+                  size_t stride, uint64_t* out_xy, uint8_t* out_inf);
+void msm_free_work(Ctx* c);
+
+// poly.hip: combined = sum_i xi^(i+1) p_i; quotient (combined - combined(z)) / (X - z).
+// d_quot receives max_len-1 coefficients (canonical words); eval_out the value combined(z).
+int open_quotient_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                         const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out,
+                         size_t* quot_len, uint64_t* eval_out);
+
+}  // namespace kzg

@@ -1,0 +1,652 @@
+// msm.hip -- KZG commitment = multi-scalar multiplication sum_i p_i * ck[i] on gfx950.
+//
+// Replaces the hot loop of the reference's KZG.commit (kzg.py:112-116: one
+// py_ecc double-and-add `multiply` per coefficient plus a running `add`) with a
+// Pippenger bucket method laid out for 288 GB of HBM:
+//
+//   SRS load (once per commitment key): for every point P_i the table holds the
+//     W = ceil(256/c) multiples 2^(c*j) * P_i in affine Montgomery form, one
+//     128-byte record each (BLS12-381; one cache line per gather).  With the
+//     multiples precomputed ALL windows feed ONE set of 2^(c-1) buckets: no
+//     per-window bucket sets, no doublings between windows at commit time.
+//   commit:
+//     1 digits      scalar -> W signed c-bit digits; entry (bucket |d|-1, table
+//                   index j*n+i, sign)                       [kzg.py:113-114 zero skip]
+//     2 sort        entries by bucket (rocPRIM radix sort on 16-bit keys)
+//     3 bounds      first entry of every bucket (binary search), slices per bucket, scan
+//     4 accumulate  one thread per slice of <= SEG entries of one bucket: gathers
+//                   records and runs mixed XYZZ additions      <- the dominant kernel
+//     5 finalize    8 lanes per bucket fold the slice partials
+//     6 reduce      sum_k k*B_k = sum_b 2^b * T_b with T_b = sum of buckets whose
+//                   index has bit b set: 15 parallel tree sums, wave shuffles
+//     7 host        Horner over the 16 T_b, one inversion to affine (O(1) work)
+//
+// c = 16: 16 digits for scalars < 2^255 (top digit cannot wrap since r < 2^255).
+#include <cstring>
+#include <string.h>
+#include <algorithm>
+#include "internal.h"
+#include "ec.h"
+#include "msm.h"
+#include <rocprim/rocprim.hpp>
+
+namespace kzg {
+
+namespace {
+
+constexpr int WIN_BITS = 16;
+constexpr int NWIN = 16;
+constexpr uint32_t NBUCKET = 1u << (WIN_BITS - 1);   // bucket k holds digit magnitude k+1
+constexpr uint32_t SEG = 32;                          // max entries per accumulate thread
+constexpr uint32_t FIN_LANES = 8;                     // lanes per bucket in finalize
+constexpr uint32_t RED_PER_LANE = 4;                  // buckets per lane in reduce stage 1
+constexpr uint32_t RED_WAVES = (NBUCKET / 2) / (64 * RED_PER_LANE);   // 64 partials per bit
+
+template <class C> struct Rec {
+  static constexpr int WORDS = C::REC_WORDS;
+  static constexpr int N = C::Fp::N;
+  static constexpr int FLAG = 2 * N;   // word index of the flags (bit 0: infinity)
+};
+
+template <class C>
+__device__ __forceinline__ void load_rec(const uint32_t* recs, size_t idx, Fe<typename C::Fp>& x,
+                                         Fe<typename C::Fp>& y) {
+  constexpr int N = C::Fp::N;
+  const uint32_t* p = recs + idx * Rec<C>::WORDS;
+  uint32_t w[2 * N];
+  if constexpr ((2 * N) % 4 == 0) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < (2 * N) / 4; ++i) {
+      const uint4 v = q[i];
+      w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+  } else {
+    const uint2* q = reinterpret_cast<const uint2*>(p);
+#pragma unroll
+    for (int i = 0; i < (2 * N) / 2; ++i) {
+      const uint2 v = q[i];
+      w[2 * i] = v.x; w[2 * i + 1] = v.y;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) { x.l[j] = w[j]; y.l[j] = w[N + j]; }
+}
+
+template <class C>
+__device__ __forceinline__ void store_rec(uint32_t* recs, size_t idx, const Fe<typename C::Fp>& x,
+                                          const Fe<typename C::Fp>& y, bool inf) {
+  constexpr int N = C::Fp::N;
+  uint32_t* p = recs + idx * Rec<C>::WORDS;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { p[j] = inf ? 0u : x.l[j]; p[N + j] = inf ? 0u : y.l[j]; }
+#pragma unroll
+  for (int j = 2 * N; j < Rec<C>::WORDS; ++j) p[j] = 0;
+  p[Rec<C>::FLAG] = inf ? 1u : 0u;
+}
+
+template <class C>
+__device__ __forceinline__ XYZZ<C> load_xyzz(const uint32_t* base, size_t idx) {
+  constexpr int N = C::Fp::N;
+  const uint32_t* p = base + idx * 4 * N;
+  XYZZ<C> r;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { r.x.l[j] = p[j]; r.y.l[j] = p[N + j]; r.zz.l[j] = p[2 * N + j]; r.zzz.l[j] = p[3 * N + j]; }
+  return r;
+}
+template <class C>
+__device__ __forceinline__ void store_xyzz(uint32_t* base, size_t idx, const XYZZ<C>& v) {
+  constexpr int N = C::Fp::N;
+  uint32_t* p = base + idx * 4 * N;
+#pragma unroll
+  for (int j = 0; j < N; ++j) { p[j] = v.x.l[j]; p[N + j] = v.y.l[j]; p[2 * N + j] = v.zz.l[j]; p[3 * N + j] = v.zzz.l[j]; }
+}
+template <class C>
+__device__ __forceinline__ XYZZ<C> shfl_xor_xyzz(const XYZZ<C>& v, int mask) {
+  constexpr int N = C::Fp::N;
+  XYZZ<C> r;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    r.x.l[j] = __shfl_xor(v.x.l[j], mask);
+    r.y.l[j] = __shfl_xor(v.y.l[j], mask);
+    r.zz.l[j] = __shfl_xor(v.zz.l[j], mask);
+    r.zzz.l[j] = __shfl_xor(v.zzz.l[j], mask);
+  }
+  return r;
+}
+
+// ---- SRS table construction ------------------------------------------------------
+
+// canonical affine words (x | y, NW 32-bit words each) -> window-0 records
+template <class C>
+__global__ void srs_import_kernel(const uint32_t* xy, const uint8_t* inf, uint32_t* recs, size_t n,
+                                  uint32_t* bad_count) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool is_inf = inf && inf[i];
+  Fe<F> x = Fd::zero(), y = Fd::zero();
+  if (!is_inf) {
+    uint32_t wx[F::NW], wy[F::NW];
+#pragma unroll
+    for (int k = 0; k < F::NW; ++k) { wx[k] = xy[i * 2 * F::NW + k]; wy[k] = xy[i * 2 * F::NW + F::NW + k]; }
+    x = Fd::reduce(Fd::to_mont(Fd::from_words(wx)));
+    y = Fd::reduce(Fd::to_mont(Fd::from_words(wy)));
+    if (!Ec<C>::on_curve(x, y)) atomicAdd(bad_count, 1u);
+  }
+  store_rec<C>(recs, i, x, y, is_inf);
+}
+
+// records of window j -> window j+1: multiply every point by 2^WIN_BITS
+template <class C>
+__global__ __launch_bounds__(128) void srs_window_kernel(const uint32_t* src, uint32_t* dst, size_t n) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<F> x, y;
+  load_rec<C>(src, i, x, y);
+  const bool is_inf = src[i * Rec<C>::WORDS + Rec<C>::FLAG] & 1u;
+  XYZZ<C> p = is_inf ? Ec<C>::infinity() : Ec<C>::dbl_affine(x, y);
+  for (int d = 1; d < WIN_BITS; ++d) p = Ec<C>::dbl(p);
+  const Affine<C> a = Ec<C>::to_affine(p);
+  store_rec<C>(dst, i, Fd::reduce(a.x), Fd::reduce(a.y), a.inf);
+}
+
+// window-0 records -> canonical affine words (kzg_srs_export)
+template <class C>
+__global__ void srs_export_kernel(const uint32_t* recs, size_t start, size_t count, uint32_t* xy, uint8_t* inf) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Fe<F> x, y;
+  load_rec<C>(recs, start + i, x, y);
+  const bool is_inf = recs[(start + i) * Rec<C>::WORDS + Rec<C>::FLAG] & 1u;
+  uint32_t wx[F::NW], wy[F::NW];
+  Fd::to_words(Fd::from_mont(x), wx);
+  Fd::to_words(Fd::from_mont(y), wy);
+#pragma unroll
+  for (int k = 0; k < F::NW; ++k) {
+    xy[i * 2 * F::NW + k] = is_inf ? 0u : wx[k];
+    xy[i * 2 * F::NW + F::NW + k] = is_inf ? 0u : wy[k];
+  }
+  inf[i] = is_inf ? 1 : 0;
+}
+
+// fixed-base table for kzg_srs_generate: tab[j][d-1] = d * 2^(8j) * G, d = 1..255, j = 0..31.
+// Block j, thread d-1; every thread recomputes 2^(8j) G (cheap, one-time, fully parallel).
+template <class C>
+__global__ __launch_bounds__(256) void gen_table_kernel(const uint32_t* g_rec, uint32_t* tab) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const uint32_t j = blockIdx.x;       // window of 8 bits
+  const uint32_t d = threadIdx.x + 1;
+  if (d > 255) return;
+  Fe<F> gx, gy;
+  load_rec<C>(g_rec, 0, gx, gy);
+  XYZZ<C> base;
+  base.x = gx; base.y = gy; base.zz = Fd::one(); base.zzz = Fd::one();
+  for (uint32_t q = 0; q < 8 * j; ++q) base = Ec<C>::dbl(base);
+  XYZZ<C> acc = Ec<C>::infinity();
+  for (int bit = 7; bit >= 0; --bit) {
+    acc = Ec<C>::dbl(acc);
+    if ((d >> bit) & 1u) acc = Ec<C>::add(acc, base);
+  }
+  const Affine<C> a = Ec<C>::to_affine(acc);
+  store_rec<C>(tab, (size_t)j * 255 + (d - 1), Fd::reduce(a.x), Fd::reduce(a.y), a.inf);
+}
+
+// SRS generation (kzg.py:70-72): record i = tau^i * G by fixed-base windows of 8 bits.
+// powers: canonical words of tau^i (computed by pow kernel below)
+template <class C>
+__global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, const uint32_t* tau_mont,
+                                                           uint32_t* recs, size_t n) {
+  using F = typename C::Fp;
+  using Fr = typename C::Fr;
+  using Fd = Field<F>;
+  using Frd = Field<Fr>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // s = tau^i (square-and-multiply on the index bits), canonical words
+  Fe<Fr> b, acc = Frd::one();
+#pragma unroll
+  for (int j = 0; j < Fr::N; ++j) b.l[j] = tau_mont[j];
+  for (size_t bits = i; bits; bits >>= 1) {
+    if (bits & 1u) acc = Frd::mul(acc, b);
+    b = Frd::mul(b, b);
+  }
+  uint32_t s[Fr::NW];
+  Frd::to_words(Frd::from_mont(acc), s);
+  XYZZ<C> p = Ec<C>::infinity();
+  for (int j = 0; j < 32; ++j) {
+    const uint32_t d = (s[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    if (d) {
+      Fe<F> x, y;
+      load_rec<C>(tab, (size_t)j * 255 + (d - 1), x, y);
+      p = Ec<C>::madd(p, x, y);
+    }
+  }
+  const Affine<C> a = Ec<C>::to_affine(p);
+  store_rec<C>(recs, i, Fd::reduce(a.x), Fd::reduce(a.y), a.inf);
+}
+
+// ---- commit pipeline ----------------------------------------------------------------
+
+// scalar i -> NWIN signed digits; entry e = j*n + i
+__global__ void msm_digits_kernel(const uint32_t* scalars, const uint32_t* recs_flags_base, uint32_t rec_words,
+                                  uint32_t flag_word, uint32_t n, uint32_t srs_n, uint16_t* keys,
+                                  uint32_t* vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 lo = sp[0], hi = sp[1];
+  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const bool pt_inf = recs_flags_base[(size_t)i * rec_words + flag_word] & 1u;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < NWIN; ++j) {
+    uint32_t d = ((w[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
+    uint32_t neg = 0;
+    if (d > (1u << (WIN_BITS - 1))) { d = (1u << WIN_BITS) - d; neg = 1; carry = 1; } else { carry = 0; }
+    const bool skip = (d == 0) || pt_inf;           // zero digit / infinity point contribute nothing
+    keys[(size_t)j * n + i] = skip ? (uint16_t)0xffff : (uint16_t)(d - 1);
+    vals[(size_t)j * n + i] = ((uint32_t)j * srs_n + i) | (neg << 31);
+  }
+}
+
+// bstart[k] = first sorted entry with key >= k, k = 0..NBUCKET  (bstart[NBUCKET] = #real entries)
+__global__ void msm_bounds_kernel(const uint16_t* keys, uint32_t m, uint32_t* bstart) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > NBUCKET) return;
+  uint32_t lo = 0, hi = m;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (keys[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  bstart[k] = lo;
+}
+
+// slice_off[k] = sum_{k' < k} ceil(len_k' / SEG), k = 0..NBUCKET.  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void msm_slices_kernel(const uint32_t* bstart, uint32_t* slice_off) {
+  __shared__ uint32_t part[1024];
+  const uint32_t t = threadIdx.x;
+  constexpr uint32_t PER = NBUCKET / 1024;
+  uint32_t cnt[PER];
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) {
+    const uint32_t k = t * PER + q;
+    const uint32_t len = bstart[k + 1] - bstart[k];
+    cnt[q] = (len + SEG - 1) / SEG;
+    sum += cnt[q];
+  }
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;   // exclusive prefix of this thread's first bucket
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) {
+    slice_off[t * PER + q] = run;
+    run += cnt[q];
+  }
+  if (t == 1023) slice_off[NBUCKET] = run;
+}
+
+template <class C>
+__global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
+                                                             const uint32_t* bstart, const uint32_t* slice_off,
+                                                             uint32_t* partials) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= slice_off[NBUCKET]) return;
+  // bucket of slice t: largest k with slice_off[k] <= t
+  uint32_t lo = 0, hi = NBUCKET;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (slice_off[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t k = lo;
+  const uint32_t s = t - slice_off[k];
+  const uint32_t ns = slice_off[k + 1] - slice_off[k];
+  const uint32_t b0 = bstart[k];
+  const uint32_t len = bstart[k + 1] - b0;
+  const uint32_t e0 = b0 + (uint32_t)(((uint64_t)s * len) / ns);
+  const uint32_t e1 = b0 + (uint32_t)(((uint64_t)(s + 1) * len) / ns);
+  XYZZ<C> acc = Ec<C>::infinity();
+  for (uint32_t e = e0; e < e1; ++e) {
+    const uint32_t v = vals[e];
+    Fe<F> x, y;
+    load_rec<C>(recs, v & 0x7fffffffu, x, y);
+    const Fe<F> yn = Fd::neg(y);
+    y = Fd::select(v >> 31, yn, y);
+    acc = Ec<C>::madd(acc, x, y);
+  }
+  store_xyzz<C>(partials, t, acc);
+}
+
+// FIN_LANES lanes per bucket fold that bucket's slice partials
+template <class C>
+__global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* partials, const uint32_t* slice_off,
+                                                           uint32_t* buckets) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = gt / FIN_LANES, g = gt % FIN_LANES;
+  XYZZ<C> acc = Ec<C>::infinity();
+  if (k < NBUCKET) {
+    const uint32_t p0 = slice_off[k], p1 = slice_off[k + 1];
+    for (uint32_t p = p0 + g; p < p1; p += FIN_LANES) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
+  }
+#pragma unroll
+  for (int m = 1; m < (int)FIN_LANES; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  if (k < NBUCKET && g == 0) store_xyzz<C>(buckets, k, acc);
+}
+
+// stage 1 of the bit-plane reduction: grid (RED_WAVES, 15); one wave per block.
+// T_b = sum of buckets whose magnitude v = k+1 has bit b set (v in 1..32767).
+template <class C>
+__global__ __launch_bounds__(64) void msm_reduce1_kernel(const uint32_t* buckets, uint32_t* bitpart) {
+  const uint32_t b = blockIdx.y, wv = blockIdx.x, lane = threadIdx.x;
+  XYZZ<C> acc = Ec<C>::infinity();
+#pragma unroll 1
+  for (uint32_t q4 = 0; q4 < RED_PER_LANE; ++q4) {
+    const uint32_t q = (wv * 64 + lane) * RED_PER_LANE + q4;       // q-th 15-bit value with bit b set
+    const uint32_t v = ((q >> b) << (b + 1)) | (1u << b) | (q & ((1u << b) - 1));
+    acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  if (lane == 0) store_xyzz<C>(bitpart, b * RED_WAVES + wv, acc);
+}
+// stage 2: one wave per bit folds RED_WAVES partials; bit 15 is the single bucket 32768
+template <class C>
+__global__ __launch_bounds__(64) void msm_reduce2_kernel(const uint32_t* bitpart, const uint32_t* buckets,
+                                                         uint32_t* tb) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  XYZZ<C> acc = Ec<C>::infinity();
+  if (b < 15) {
+    if (lane < RED_WAVES) acc = load_xyzz<C>(bitpart, b * RED_WAVES + lane);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  } else {
+    acc = load_xyzz<C>(buckets, NBUCKET - 1);
+  }
+  if (lane == 0) store_xyzz<C>(tb, b, acc);
+}
+
+template <class C>
+size_t rec_bytes() { return (size_t)C::REC_WORDS * 4; }
+
+struct SortTemp {
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+// ---- host-side drivers ----------------------------------------------------------------
+
+template <class C>
+static int srs_build_windows(Ctx* c, Srs* s) {
+  const size_t n = s->n;
+  const uint32_t blocks = (uint32_t)((n + 127) / 128);
+  for (int j = 1; j < NWIN; ++j) {
+    hipLaunchKernelGGL(srs_window_kernel<C>, dim3(blocks), dim3(128), 0, c->stream,
+                       s->recs + (size_t)(j - 1) * n * C::REC_WORDS, s->recs + (size_t)j * n * C::REC_WORDS, n);
+    KZG_HIP(c, hipGetLastError());
+  }
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  return KZG_OK;
+}
+
+template <class C>
+static int srs_load_t(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
+  using F = typename C::Fp;
+  if (n == 0 || n * (size_t)NWIN >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_load_g1: bad size");
+  Srs* s = new Srs();
+  s->n = n;
+  s->curve = c->curve;
+  const size_t table_bytes = (size_t)NWIN * n * rec_bytes<C>();
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->recs), table_bytes);
+  if (e != hipSuccess) { delete s; return set_err(c, KZG_ERR_ALLOC, "hipMalloc(SRS table)", e); }
+  uint32_t* d_xy = nullptr; uint8_t* d_inf = nullptr; uint32_t* d_bad = nullptr;
+  const size_t xy_bytes = n * 2 * F::NW * 4;
+  auto cleanup = [&]() { hipFree(d_xy); hipFree(d_inf); hipFree(d_bad); };
+  auto fail = [&](int rc) { cleanup(); hipFree(s->recs); delete s; return rc; };
+  if (hipMalloc(reinterpret_cast<void**>(&d_xy), xy_bytes) != hipSuccess) return fail(set_err(c, KZG_ERR_ALLOC, "hipMalloc"));
+  if (hipMalloc(reinterpret_cast<void**>(&d_bad), 4) != hipSuccess) return fail(set_err(c, KZG_ERR_ALLOC, "hipMalloc"));
+  if (inf && hipMalloc(reinterpret_cast<void**>(&d_inf), n) != hipSuccess) return fail(set_err(c, KZG_ERR_ALLOC, "hipMalloc"));
+  hipMemcpyAsync(d_xy, xy, xy_bytes, hipMemcpyHostToDevice, c->stream);
+  if (inf) hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, c->stream);
+  hipMemsetAsync(d_bad, 0, 4, c->stream);
+  hipLaunchKernelGGL(srs_import_kernel<C>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_xy, d_inf,
+                     s->recs, n, d_bad);
+  uint32_t bad = 0;
+  hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
+  e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(set_err(c, KZG_ERR_HIP, "srs import", e));
+  if (bad) return fail(set_err(c, KZG_ERR_ARG, "kzg_srs_load_g1: point not on the curve"));
+  cleanup();
+  int rc = srs_build_windows<C>(c, s);
+  if (rc) { hipFree(s->recs); delete s; return rc; }
+  *out = s;
+  return KZG_OK;
+}
+
+template <class C>
+static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t n, const uint64_t* gen_xy, Srs** out) {
+  using F = typename C::Fp;
+  using Fr = typename C::Fr;
+  if (n == 0 || n * (size_t)NWIN >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_generate: bad size");
+  Srs* s = new Srs();
+  s->n = n;
+  s->curve = c->curve;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->recs), (size_t)NWIN * n * rec_bytes<C>());
+  if (e != hipSuccess) { delete s; return set_err(c, KZG_ERR_ALLOC, "hipMalloc(SRS table)", e); }
+  uint32_t *d_g = nullptr, *d_tab = nullptr, *d_tau = nullptr, *d_xy = nullptr, *d_bad = nullptr;
+  auto cleanup = [&]() { hipFree(d_g); hipFree(d_tab); hipFree(d_tau); hipFree(d_xy); hipFree(d_bad); };
+  auto fail = [&](int rc) { cleanup(); hipFree(s->recs); delete s; return rc; };
+  if (hipMalloc(reinterpret_cast<void**>(&d_g), rec_bytes<C>()) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_tab), 32 * 255 * rec_bytes<C>()) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_tau), Fr::N * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_xy), 2 * F::NW * 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&d_bad), 4) != hipSuccess)
+    return fail(set_err(c, KZG_ERR_ALLOC, "hipMalloc"));
+  const Fe<Fr> tau = Field<Fr>::to_mont(Field<Fr>::from_words(tau_words));
+  hipMemcpy(d_tau, tau.l, Fr::N * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_xy, gen_xy, 2 * F::NW * 4, hipMemcpyHostToDevice);
+  hipMemsetAsync(d_bad, 0, 4, c->stream);
+  hipLaunchKernelGGL(srs_import_kernel<C>, dim3(1), dim3(64), 0, c->stream, d_xy, (const uint8_t*)nullptr, d_g,
+                     (size_t)1, d_bad);
+  hipLaunchKernelGGL(gen_table_kernel<C>, dim3(32), dim3(256), 0, c->stream, d_g, d_tab);
+  hipLaunchKernelGGL(srs_generate_kernel<C>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, c->stream, d_tab, d_tau,
+                     s->recs, n);
+  e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(set_err(c, KZG_ERR_HIP, "srs generate", e));
+  cleanup();
+  int rc = srs_build_windows<C>(c, s);
+  if (rc) { hipFree(s->recs); delete s; return rc; }
+  *out = s;
+  return KZG_OK;
+}
+
+static const uint64_t GEN_BN254[8] = {1, 0, 0, 0, 2, 0, 0, 0};
+static const uint64_t GEN_BLS[12] = {
+    0xfb3af00adb22c6bbull, 0x6c55e83ff97a1aefull, 0xa14e3a3f171bac58ull, 0xc3688c4f9774b905ull,
+    0x2695638c4fa9ac0full, 0x17f1d3a73197d794ull,
+    0x0caa232946c5e7e1ull, 0xd03cc744a2888ae4ull, 0x00db18cb2c04b3edull, 0xfcf5e095d5d00af6ull,
+    0xa09e30ed741d8ae4ull, 0x08b3f481e3aaa0f1ull};
+
+int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
+  return c->curve == 0 ? srs_load_t<Bn254>(c, xy, inf, n, out) : srs_load_t<Bls12_381>(c, xy, inf, n, out);
+}
+int srs_generate(Ctx* c, const uint64_t* tau, size_t n, Srs** out) {
+  const uint32_t* t = reinterpret_cast<const uint32_t*>(tau);
+  return c->curve == 0 ? srs_generate_t<Bn254>(c, t, n, GEN_BN254, out)
+                       : srs_generate_t<Bls12_381>(c, t, n, GEN_BLS, out);
+}
+void srs_free(Srs* s) {
+  if (!s) return;
+  hipFree(s->recs);
+  delete s;
+}
+
+template <class C>
+static int srs_export_t(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, uint8_t* inf) {
+  using F = typename C::Fp;
+  if (start + count > s->n) return set_err(c, KZG_ERR_ARG, "kzg_srs_export: range");
+  if (count == 0) return KZG_OK;
+  uint32_t* d_xy = nullptr; uint8_t* d_inf = nullptr;
+  KZG_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_xy), count * 2 * F::NW * 4));
+  KZG_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_inf), count));
+  hipLaunchKernelGGL(srs_export_kernel<C>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, c->stream, s->recs,
+                     start, count, d_xy, d_inf);
+  hipMemcpyAsync(xy, d_xy, count * 2 * F::NW * 4, hipMemcpyDeviceToHost, c->stream);
+  hipMemcpyAsync(inf, d_inf, count, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  hipFree(d_xy); hipFree(d_inf);
+  if (e != hipSuccess) return set_err(c, KZG_ERR_HIP, "srs export", e);
+  return KZG_OK;
+}
+int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, uint8_t* inf) {
+  return c->curve == 0 ? srs_export_t<Bn254>(c, s, start, count, xy, inf)
+                       : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
+}
+
+// workspace for one in-flight commit
+struct MsmWork {
+  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart, slice_off, partials, buckets, bitpart, tb;
+  void* h_tb = nullptr;       // pinned host copy of the 16 T_b
+  size_t cap_n = 0;
+};
+
+static MsmWork* get_work(Ctx* c) {
+  if (!c->msm_work) c->msm_work = new MsmWork();
+  return static_cast<MsmWork*>(c->msm_work);
+}
+void msm_free_work(Ctx* c) {
+  MsmWork* w = static_cast<MsmWork*>(c->msm_work);
+  if (!w) return;
+  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart, &w->slice_off,
+                    &w->partials, &w->buckets, &w->bitpart, &w->tb})
+    hipFree(b->p);
+  if (w->h_tb) hipHostFree(w->h_tb);
+  delete w;
+  c->msm_work = nullptr;
+}
+
+template <class C>
+static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w) {
+  constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
+  const uint32_t m = n * NWIN;
+  const uint32_t max_slices = m / SEG + NBUCKET + 1;
+  int rc;
+  if ((rc = ensure_buf(c, w->keys_a, (size_t)m * 2))) return rc;
+  if ((rc = ensure_buf(c, w->keys_b, (size_t)m * 2))) return rc;
+  if ((rc = ensure_buf(c, w->vals_a, (size_t)m * 4))) return rc;
+  if ((rc = ensure_buf(c, w->vals_b, (size_t)m * 4))) return rc;
+  if ((rc = ensure_buf(c, w->bstart, (NBUCKET + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, w->slice_off, (NBUCKET + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, w->partials, (size_t)max_slices * PT))) return rc;
+  if ((rc = ensure_buf(c, w->buckets, (size_t)NBUCKET * PT))) return rc;
+  if ((rc = ensure_buf(c, w->bitpart, (size_t)15 * RED_WAVES * PT))) return rc;
+  if ((rc = ensure_buf(c, w->tb, (size_t)16 * PT))) return rc;
+  if (!w->h_tb) KZG_HIP(c, hipHostMalloc(&w->h_tb, 16 * 4 * 14 * 4));
+
+  auto* keys_a = static_cast<uint16_t*>(w->keys_a.p);
+  auto* keys_b = static_cast<uint16_t*>(w->keys_b.p);
+  auto* vals_a = static_cast<uint32_t*>(w->vals_a.p);
+  auto* vals_b = static_cast<uint32_t*>(w->vals_b.p);
+  size_t tmp_bytes = 0;
+  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
+                                       c->stream));
+  if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
+
+  hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_scalars, s->recs,
+                     (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
+  KZG_HIP(c, hipGetLastError());
+  KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
+                                       c->stream));
+  auto* bstart = static_cast<uint32_t*>(w->bstart.p);
+  auto* slice_off = static_cast<uint32_t*>(w->slice_off.p);
+  hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, c->stream, keys_b, m, bstart);
+  hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, c->stream, bstart, slice_off);
+  hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, c->stream, s->recs,
+                     vals_b, bstart, slice_off, static_cast<uint32_t*>(w->partials.p));
+  hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, c->stream,
+                     static_cast<uint32_t*>(w->partials.p), slice_off, static_cast<uint32_t*>(w->buckets.p));
+  hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, c->stream,
+                     static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->bitpart.p));
+  hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, c->stream, static_cast<uint32_t*>(w->bitpart.p),
+                     static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->tb.p));
+  KZG_HIP(c, hipGetLastError());
+  KZG_HIP(c, hipMemcpyAsync(w->h_tb, w->tb.p, 16 * PT, hipMemcpyDeviceToHost, c->stream));
+  return KZG_OK;
+}
+
+// host: sum_b 2^b T_b, to affine, canonical words
+template <class C>
+static void msm_finish_host(const void* h_tb, uint64_t* out_xy, uint8_t* out_inf) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  constexpr int N = F::N;
+  const uint32_t* p = static_cast<const uint32_t*>(h_tb);
+  XYZZ<C> acc = Ec<C>::infinity();
+  for (int b = 15; b >= 0; --b) {
+    acc = Ec<C>::dbl(acc);
+    XYZZ<C> t;
+    memcpy(t.x.l, p + (size_t)b * 4 * N, N * 4);
+    memcpy(t.y.l, p + (size_t)b * 4 * N + N, N * 4);
+    memcpy(t.zz.l, p + (size_t)b * 4 * N + 2 * N, N * 4);
+    memcpy(t.zzz.l, p + (size_t)b * 4 * N + 3 * N, N * 4);
+    acc = Ec<C>::add(acc, t);
+  }
+  const Affine<C> a = Ec<C>::to_affine(acc);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out_xy);
+  if (a.inf) {
+    memset(o, 0, 2 * F::NW * 4);
+    *out_inf = 1;
+    return;
+  }
+  Fd::to_words(Fd::from_mont(a.x), o);
+  Fd::to_words(Fd::from_mont(a.y), o + F::NW);
+  *out_inf = 0;
+}
+
+template <class C>
+static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
+                    size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+  using F = typename C::Fp;
+  MsmWork* w = get_work(c);
+  for (size_t p = 0; p < n_polys; ++p) {
+    if (lens[p] > s->n) return set_err(c, KZG_ERR_DEGREE, "polynomial longer than the commitment key");
+    if (lens[p] > stride) return set_err(c, KZG_ERR_ARG, "kzg_commit: lens[p] > stride");
+  }
+  for (size_t p = 0; p < n_polys; ++p) {
+    uint64_t* o = out_xy + p * 2 * (F::NW / 2);
+    if (lens[p] == 0) {   // zero polynomial: Z1 (kzg.py:109)
+      memset(o, 0, 2 * F::NW * 4);
+      out_inf[p] = 1;
+      continue;
+    }
+    int rc = msm_enqueue<C>(c, s, d_scalars + p * stride * 8, (uint32_t)lens[p], w);
+    if (rc) return rc;
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+    msm_finish_host<C>(w->h_tb, o, out_inf + p);
+  }
+  return KZG_OK;
+}
+
+int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
+                  size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+  if (s->curve != c->curve) return set_err(c, KZG_ERR_ARG, "SRS belongs to another curve");
+  return c->curve == 0 ? commit_t<Bn254>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf)
+                       : commit_t<Bls12_381>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf);
+}
+
+}  // namespace kzg

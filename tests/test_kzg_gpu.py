@@ -1,0 +1,196 @@
+"""GPU parity of SRS generation, KZG.commit and KZG.open (csrc/msm.hip, csrc/poly.hip
+through the C ABI and the KZG facade) against the oracle's restatement of kzg.py.
+Bit-exact on affine coordinates (integer work; SURVEY.md 7.2: projective
+representatives are not comparable, affine points are)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import py_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bls12_381", "bn254"]
+
+
+def aff(pt):
+    """facade point -> oracle-style affine (x, y) or None."""
+    return None if pt[2] == 0 else (pt[0], pt[1])
+
+
+@pytest.fixture(scope="module")
+def kzgs():
+    from kzg_snark_amd.kzg import KZG
+    return {c: KZG(c) for c in CURVES}
+
+
+@pytest.fixture(scope="module")
+def small_keys(kzgs):
+    out = {}
+    for c in CURVES:
+        tau = 0x1234567890abcdef1234567890abcdef % O.curve(c).r
+        ck, tau_g2 = kzgs[c].setup(63, tau=tau)
+        out[c] = (ck, tau)
+    return out
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_setup_matches_oracle(kzgs, small_keys, curve):
+    cv = O.curve(curve)
+    ck, tau = small_keys[curve]
+    assert len(ck) == 64
+    ref = O.setup(63, tau, cv)
+    for i in (0, 1, 2, 3, 31, 62, 63):
+        assert aff(ck[i]) == O.normalize(ref[i], cv), i
+    assert ck[0] == kzgs[curve].G1
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_commit_matches_oracle(kzgs, small_keys, curve):
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    ck, tau = small_keys[curve]
+    rng = random.Random(11)
+    ref_ck = O.setup(63, tau, cv)
+    polys = [
+        [rng.randrange(cv.r) for _ in range(64)],
+        [rng.randrange(cv.r) for _ in range(17)],
+        [0, 0, 5, 0, cv.r - 1],                       # zero coefficients are skipped (kzg.py:113-114)
+        [1] * 64,
+        [0] * 63 + [1],
+        [cv.r - 1] * 9,
+        [7],
+    ]
+    got = kzg.commit(ck, polys)
+    want = O.commit(ref_ck, polys, cv)
+    for g, w in zip(got, want):
+        assert aff(g) == O.normalize(w, cv)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_commit_edge_cases(kzgs, small_keys, curve):
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    ck, tau = small_keys[curve]
+    assert kzg.commit(ck, [[]]) == [kzg.Z1]                    # zero polynomial (kzg.py:109)
+    assert kzg.commit(ck, [[0, 0, 0]]) == [kzg.Z1]
+    assert kzg.commit(ck, []) == []
+    assert kzg.commit(ck, [[5] + [0] * 100]) == kzg.commit(ck, [[5]])    # trailing zeros are not degree
+    with pytest.raises(ValueError):                            # kzg.py:103-106
+        kzg.commit(ck, [[1] * 65])
+    # polynomial objects (R(list)) are accepted like lists (kzg.py:93-97)
+    p = kzg.R([3, 0, 9])
+    assert kzg.commit(ck, [p]) == kzg.commit(ck, [[3, 0, 9]])
+    # p(X) and -p(X) commit to opposite points; their sum is the zero polynomial
+    a = kzg.commit(ck, [[1, 2, 3]])[0]
+    b = kzg.commit(ck, [[cv.r - 1, cv.r - 2, cv.r - 3]])[0]
+    assert kzg.add(a, b) == kzg.Z1
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_commit_with_plain_list_key_duplicates_and_infinity(kzgs, curve):
+    """`ck` given the way the reference's callers hold it (a list of point tuples),
+    with duplicate points (forces P+P inside a bucket) and a point at infinity."""
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    g = O.from_affine(cv.g1)
+    pts = [g, g, O.double(g, cv), g, O.Z1(), O.multiply(g, 5, cv), O.neg(g, cv), g]
+    ck = []
+    for p in pts:
+        n = O.normalize(p, cv)
+        ck.append((1, 1, 0) if n is None else (n[0], n[1], 1))
+    rng = random.Random(5)
+    polys = [[3, 3, 3, 3, 9, 1, 3, 3],            # equal digits on equal points -> doubling in a bucket
+             [1, 1, 0, 0, 0, 0, 2, 0],            # G + G - 2G = O
+             [rng.randrange(cv.r) for _ in range(8)]]
+    got = kzg.commit(ck, polys)
+    want = O.commit(pts, polys, cv)
+    for g_, w in zip(got, want):
+        assert aff(g_) == O.normalize(w, cv)
+    assert got[1] == kzg.Z1
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_open_matches_oracle(kzgs, small_keys, curve):
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    ck, tau = small_keys[curve]
+    ref_ck = O.setup(63, tau, cv)
+    rng = random.Random(21)
+    for lens in ([64], [64, 40, 7], [5, 64], [1], [2, 1], [33], [64] * 7):
+        polys = [[rng.randrange(cv.r) for _ in range(n)] for n in lens]
+        z, xi = rng.randrange(cv.r), rng.randrange(cv.r)
+        got = kzg.open(ck, polys, z, xi)
+        want, _ = O.open_(ref_ck, polys, z, xi, cv)
+        assert aff(got) == O.normalize(want, cv), lens
+        assert aff(got) == O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
+    # z = 0, xi = 0, z = a root of the polynomial
+    polys = [[rng.randrange(cv.r) for _ in range(10)]]
+    for z, xi in ((0, 5), (7, 0), (0, 0), (cv.r - 1, 1)):
+        got = kzg.open(ck, polys, z, xi)
+        want, _ = O.open_(ref_ck, polys, z, xi, cv)
+        assert aff(got) == O.normalize(want, cv), (z, xi)
+    assert kzg.open(ck, [[4]], 3, 2) == kzg.Z1          # constant polynomial: witness is 0
+
+
+def test_open_returns_evaluation(native, small_keys):
+    cv = O.BLS12_381
+    ck, tau = small_keys["bls12_381"]
+    rng = random.Random(3)
+    polys = [[rng.randrange(cv.r) for _ in range(n)] for n in (50, 20)]
+    z, xi = rng.randrange(cv.r), rng.randrange(cv.r)
+    arr = np.zeros((2, 50, 4), dtype=np.uint64)
+    for i, p in enumerate(polys):
+        arr[i, :len(p)] = native.ints_to_limbs(p)
+    ctx = native.get_context("bls12_381")
+    xy, inf, ev = ctx.open(ck.srs, arr, [50, 20], 50, native.int_to_words(z), native.int_to_words(xi))
+    assert native.limbs_to_ints(ev.reshape(1, 4))[0] == O.poly_eval(O.combine(polys, xi, cv.r), z, cv.r)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_commit_medium_trapdoor(kzgs, curve):
+    """n = 2^12 + 3 (not a power of two, like the provers' n+2..n+6): trapdoor identity."""
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    tau = 0xdeadbeefcafebabe0123456789 % cv.r
+    n = (1 << 12) + 3
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    rng = random.Random(77)
+    p = [rng.randrange(cv.r) for _ in range(n)]
+    got = kzg.commit(ck, [p])[0]
+    assert aff(got) == O.normalize(O.commit_trapdoor(p, tau, cv), cv)
+    small = [rng.randrange(3) for _ in range(n)]          # PLONK-like: many 0 / 1 / 2 scalars
+    assert aff(kzg.commit(ck, [small])[0]) == O.normalize(O.commit_trapdoor(small, tau, cv), cv)
+
+
+def test_commit_full_size_2_20_trapdoor(native, kzgs):
+    """BASELINE config 3: degree-2^20 commit on BLS12-381 against a 2^20-point SRS.
+    The oracle's naive commit is hours at this size; parity is the trapdoor
+    identity commit(ck, p) == p(tau)*G1, plus spot checks
+    of the generated SRS against tau^i * G1."""
+    cv = O.BLS12_381
+    kzg = kzgs["bls12_381"]
+    n = 1 << 20
+    tau = 0x6b7a675f736e61726b7a675f736e6172 % cv.r
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    g = O.from_affine(cv.g1)
+    for i in (0, 1, 2, 65537, n - 1):
+        assert aff(ck[i]) == O.normalize(O.multiply(g, pow(tau, i, cv.r), cv), cv), i
+    rs = np.random.RandomState(9)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(3)
+    coeffs = native.limbs_to_ints(raw)
+    ctx = native.get_context("bls12_381")
+    xy, inf = ctx.commit(ck.srs, raw.reshape(1, n, 4), [n], n)
+    assert inf[0] == 0
+    got = native.limbs_to_ints(xy.reshape(2, 6))
+    want = O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+    assert (got[0], got[1]) == want
+    # open at full size: trapdoor identity for the witness
+    z, xi = 0x1111111111111111111111111111 % cv.r, 0x2222222222222222222222 % cv.r
+    oxy, oinf, ev = ctx.open(ck.srs, raw.reshape(1, n, 4), [n], n, native.int_to_words(z), native.int_to_words(xi))
+    got = native.limbs_to_ints(oxy.reshape(2, 6))
+    want = O.normalize(O.open_trapdoor([coeffs], z, xi, tau, cv), cv)
+    assert (got[0], got[1]) == want
+    assert native.limbs_to_ints(ev.reshape(1, 4))[0] == xi * O.poly_eval(coeffs, z, cv.r) % cv.r

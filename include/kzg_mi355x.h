@@ -116,6 +116,15 @@ int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const
                     size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
                     uint64_t* eval_out);
 
+/* ---- measurement hooks (bench.py) -----------------------------------------------------------
+ * When enabled, the library brackets its kernels with HIP events on the context's stream.
+ * Span names: "ntt_pass", "msm_digits", "msm_sort", "msm_bounds", "msm_accumulate",
+ * "msm_finalize", "msm_reduce", "open_poly".  kzg_prof_read synchronises the stream and returns
+ * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset. */
+int kzg_prof_enable(kzg_ctx* ctx, int on);
+int kzg_prof_reset(kzg_ctx* ctx);
+int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,10 @@ SIGNATURES = {
     "kzg_commit": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_open": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "kzg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "kzg_prof_reset": (ctypes.c_int, [_vp]),
+    "kzg_prof_read": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_open_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -125,6 +129,19 @@ class Context:
 
     def synchronize(self):
         self._check(lib().kzg_ctx_synchronize(self._h))
+
+    # ---- measurement hooks
+    def prof_enable(self, on=True):
+        self._check(lib().kzg_prof_enable(self._h, int(bool(on))))
+
+    def prof_reset(self):
+        self._check(lib().kzg_prof_reset(self._h))
+
+    def prof_read(self, name):
+        """(total milliseconds, launches) of one span since the last reset."""
+        ms, cnt = ctypes.c_double(0), ctypes.c_uint64(0)
+        self._check(lib().kzg_prof_read(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
 
     # ---- NTT
     def ntt(self, data, log_n, w_words, inverse):

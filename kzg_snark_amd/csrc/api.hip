@@ -30,6 +30,24 @@ int set_err(Ctx* c, int code, const char* what, hipError_t e) {
   return code;
 }
 
+ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
+  if (!c->prof_on) return;
+  for (auto& sp : c->prof)
+    if (sp.name == name) { span = &sp; break; }
+  if (!span) {
+    c->prof.reserve(64);   // spans are referenced by pointer while alive
+    c->prof.push_back(ProfSpan{name, {}, 0, 0});
+    span = &c->prof.back();
+  }
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { span = nullptr; return; }
+  hipEventRecord(e0, c->stream);
+}
+ProfScope::~ProfScope() {
+  if (!span) return;
+  hipEventRecord(e1, c->stream);
+  span->pending.emplace_back(e0, e1);
+}
+
 int ensure_buf(Ctx* c, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes) return KZG_OK;
   if (b.p) {
@@ -247,6 +265,47 @@ int kzg_open(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* polys, const size
   if (rc) return rc;
   if (bytes) KZG_HIP(c, hipMemcpyAsync(c->io.p, polys, bytes, hipMemcpyHostToDevice, c->stream));
   return kzg_open_device(ctx, srs, c->io.p, lens, k, stride, z, xi, out_xy, out_inf, eval_out);
+}
+
+int kzg_prof_enable(kzg_ctx* ctx, int on) {
+  if (!ctx) return KZG_ERR_ARG;
+  ctx->c.prof_on = on != 0;
+  return KZG_OK;
+}
+
+int kzg_prof_reset(kzg_ctx* ctx) {
+  if (!ctx) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& sp : c->prof) {
+    for (auto& pr : sp.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    sp.pending.clear();
+    sp.total_ms = 0;
+    sp.count = 0;
+  }
+  return KZG_OK;
+}
+
+int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* count) {
+  if (!ctx || !name || !total_ms || !count) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  *total_ms = 0;
+  *count = 0;
+  for (auto& sp : c->prof) {
+    if (sp.name != name) continue;
+    for (auto& pr : sp.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { sp.total_ms += ms; sp.count += 1; }
+      hipEventDestroy(pr.first);
+      hipEventDestroy(pr.second);
+    }
+    sp.pending.clear();
+    *total_ms = sp.total_ms;
+    *count = sp.count;
+    return KZG_OK;
+  }
+  return KZG_OK;
 }
 
 }  // extern "C"

@@ -33,6 +33,15 @@ struct NttDomain {
   uint64_t last_use = 0;
 };
 
+// Optional per-kernel timing with HIP events on the context's stream (bench.py's roofline
+// leg): each named span accumulates elapsed ms and a launch count.
+struct ProfSpan {
+  std::string name;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0;
+  uint64_t count = 0;
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -50,11 +59,21 @@ struct Ctx {
   DevBuf io;              // staging for the host-pointer entry points
   DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
   void* msm_work = nullptr;               // MsmWork (msm.hip)
+  bool prof_on = false;
+  std::vector<ProfSpan> prof;
   std::vector<hipStream_t> aux_streams;   // commit pipeline
   std::vector<hipEvent_t> aux_events;
 };
 
 int set_err(Ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+// RAII span: records an event pair around the launches issued while it is alive (no-op when profiling is off)
+struct ProfScope {
+  Ctx* c;
+  ProfSpan* span = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(Ctx* ctx, const char* name);
+  ~ProfScope();
+};
 int ensure_buf(Ctx* c, DevBuf& b, size_t bytes);
 
 #define KZG_HIP(c, call)                                         \

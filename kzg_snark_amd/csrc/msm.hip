@@ -567,23 +567,41 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
                                        c->stream));
   if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
 
-  hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_scalars, s->recs,
-                     (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
+  {
+    ProfScope ps(c, "msm_digits");
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_scalars, s->recs,
+                       (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
+  }
   KZG_HIP(c, hipGetLastError());
-  KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
-                                       c->stream));
+  {
+    ProfScope ps(c, "msm_sort");
+    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
+                                         c->stream));
+  }
   auto* bstart = static_cast<uint32_t*>(w->bstart.p);
   auto* slice_off = static_cast<uint32_t*>(w->slice_off.p);
-  hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, c->stream, keys_b, m, bstart);
-  hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, c->stream, bstart, slice_off);
-  hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, c->stream, s->recs,
-                     vals_b, bstart, slice_off, static_cast<uint32_t*>(w->partials.p));
-  hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, c->stream,
-                     static_cast<uint32_t*>(w->partials.p), slice_off, static_cast<uint32_t*>(w->buckets.p));
-  hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, c->stream,
-                     static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->bitpart.p));
-  hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, c->stream, static_cast<uint32_t*>(w->bitpart.p),
-                     static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->tb.p));
+  {
+    ProfScope ps(c, "msm_bounds");
+    hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, c->stream, keys_b, m, bstart);
+    hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, c->stream, bstart, slice_off);
+  }
+  {
+    ProfScope ps(c, "msm_accumulate");
+    hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, c->stream, s->recs,
+                       vals_b, bstart, slice_off, static_cast<uint32_t*>(w->partials.p));
+  }
+  {
+    ProfScope ps(c, "msm_finalize");
+    hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, c->stream,
+                       static_cast<uint32_t*>(w->partials.p), slice_off, static_cast<uint32_t*>(w->buckets.p));
+  }
+  {
+    ProfScope ps(c, "msm_reduce");
+    hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, c->stream,
+                       static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->bitpart.p));
+    hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, c->stream, static_cast<uint32_t*>(w->bitpart.p),
+                       static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->tb.p));
+  }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipMemcpyAsync(w->h_tb, w->tb.p, 16 * PT, hipMemcpyDeviceToHost, c->stream));
   return KZG_OK;

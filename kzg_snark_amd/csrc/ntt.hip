@@ -221,6 +221,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       lds_attr_set = true;
     }
+    ProfScope ps(c, "ntt_pass");
     hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
     KZG_HIP(c, hipGetLastError());
     return KZG_OK;

@@ -196,6 +196,7 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
   KZG_HIP(c, hipMemcpyAsync(d_sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
   KZG_HIP(c, hipStreamSynchronize(c->stream));     // hs is a local vector
 
+  ProfScope ps(c, "open_poly");
   LincombArgs la{};
   la.polys = d_polys; la.stride = stride; la.k = (uint32_t)k;
   for (size_t i = 0; i < k; ++i) la.lens[i] = (uint32_t)lens[i];

@@ -2,6 +2,7 @@
 // gfx950 kernels use) through a tiny C interface so tests/test_field_host.py can
 // check it against Python integers without a GPU.  Test infrastructure only.
 #include "../../kzg_snark_amd/csrc/field.h"
+#include "../../kzg_snark_amd/csrc/ec.h"
 using namespace kzg;
 
 template <class F>
@@ -43,5 +44,47 @@ extern "C" int shim_is_zero(int field, const uint32_t* a) {
     case 2: return Field<BlsFr>::is_zero(Field<BlsFr>::from_words(a));
     case 3: return Field<BlsFp>::is_zero(Field<BlsFp>::from_words(a));
   }
+  return -1;
+}
+
+// ---- ec.h ---------------------------------------------------------------------------------
+template <class C>
+static int ec_op(int which, const uint32_t* p1, int inf1, const uint32_t* p2, int inf2, uint32_t* out, int* out_inf) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  using E = Ec<C>;
+  auto load = [](const uint32_t* w, int inf) {
+    Affine<C> a;
+    a.inf = inf != 0;
+    a.x = inf ? Fd::zero() : Fd::to_mont(Fd::from_words(w));
+    a.y = inf ? Fd::zero() : Fd::to_mont(Fd::from_words(w + F::NW));
+    return a;
+  };
+  const Affine<C> A = load(p1, inf1), B = load(p2, inf2);
+  XYZZ<C> R;
+  switch (which) {
+    case 0: R = B.inf ? E::from_affine(A) : E::madd(E::from_affine(A), B.x, B.y); break;
+    case 1: R = E::add(E::from_affine(A), E::from_affine(B)); break;
+    case 2: R = E::dbl(E::from_affine(A)); break;
+    case 3: {  // ((A + B) + B) + A with a projective accumulator
+      XYZZ<C> t = E::madd(E::from_affine(A), B.x, B.y);
+      t = E::madd(t, B.x, B.y);
+      R = E::add(t, E::from_affine(A));
+      break;
+    }
+    default: return -1;
+  }
+  const Affine<C> r = E::to_affine(R);
+  *out_inf = r.inf ? 1 : 0;
+  if (!r.inf) {
+    Fd::to_words(Fd::from_mont(r.x), out);
+    Fd::to_words(Fd::from_mont(r.y), out + F::NW);
+  }
+  return 0;
+}
+extern "C" int shim_ec_op(int curve, int which, const uint32_t* p1, int inf1, const uint32_t* p2, int inf2,
+                          uint32_t* out, int* out_inf) {
+  if (curve == 0) return ec_op<Bn254>(which, p1, inf1, p2, inf2, out, out_inf);
+  if (curve == 1) return ec_op<Bls12_381>(which, p1, inf1, p2, inf2, out, out_inf);
   return -1;
 }

@@ -1,0 +1,61 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/kzg_mi355x.h declares; the ctypes table binds exactly that set.
+No compute calls here (CPU suite)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "kzg_mi355x.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kzg_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from kzg_snark_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    missing = [s for s in header_symbols() if s not in exported]
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header(built):
+    from kzg_snark_amd import _native
+    assert sorted(_native.SIGNATURES) == header_symbols()
+    L = _native.lib()
+    assert _native.MISSING == []
+    assert L.kzg_abi_version() == 1
+    assert L.kzg_fp_limbs(0) == 4 and L.kzg_fp_limbs(1) == 6 and L.kzg_fp_limbs(7) == 0
+
+
+def test_no_cpu_fallback(built):
+    """Without a GPU a context cannot be created -- loudly.  (On a GPU box it can.)"""
+    from kzg_snark_amd import _native
+    try:
+        ctx = _native.Context("bls12_381")
+    except _native.NativeUnavailable as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        ctx.close()
+    with pytest.raises(ValueError):
+        _native.Context("secp256k1")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "kzg_snark_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f

@@ -1,0 +1,96 @@
+"""Host-side logic of the facade (kzg_snark_amd/field.py, curve.py, fft_ff.py, kzg.py)
+that needs no GPU: the Sage-free field/polynomial shim, the py_ecc-shaped point
+helpers, and the reference's error behaviour at the boundary."""
+import random
+
+import pytest
+
+from kzg_snark_amd import curve as C
+from kzg_snark_amd.field import GF, PolynomialRing
+from oracle import py_oracle as O
+
+
+def test_field_shim():
+    F = GF(O.BLS12_381.r)
+    a, b = F(5), F(-3)
+    assert int(a + b) == 2 and int(a - 7) == O.BLS12_381.r - 2 and int(a * b) == O.BLS12_381.r - 15
+    assert a / b * b == a and a ** (-1) * a == F(1) and int(2 - a) == O.BLS12_381.r - 3
+    assert F(1) == 1 and F(0) == 0 and not F(0) and int(F(a)) == 5
+    g = F.root_of_unity(1 << 10)
+    assert int(g) == O.BLS12_381.root_of_unity(1 << 10)
+    assert g.multiplicative_order() == 1 << 10
+    assert (g * g).multiplicative_order() == 1 << 9
+    assert int(F.multiplicative_generator()) == 7 and int(GF(O.BN254.r).multiplicative_generator()) == 5
+    assert 0 <= int(F.random_element()) < O.BLS12_381.r
+
+
+def test_polynomial_shim():
+    F = GF(O.BN254.r)
+    R = PolynomialRing(F, "X")
+    X = R.gen()
+    p = R([1, 2, 3, 0, 0])
+    assert p.degree() == 2 and p.list() == [F(1), F(2), F(3)]
+    assert R(0).degree() == -1 and R([]).list() == []
+    assert p(2) == F(17)
+    q = (p - p(5)) // (X - 5)
+    assert q * (X - 5) + p(5) == p
+    assert (p * p) % p == R(0) and (p * p) / p == p
+    assert 3 * p == p * 3 == p + p + p
+    assert F(2) * p == p + p
+    rng = random.Random(4)
+    a = R([rng.randrange(O.BN254.r) for _ in range(9)])
+    b = R([rng.randrange(O.BN254.r) for _ in range(4)])
+    qq, rr = divmod(a, b)
+    assert qq * b + rr == a and rr.degree() < b.degree()
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_point_helpers_match_oracle(name):
+    cv, ocv = C.CURVES[name], O.curve(name)
+    G = C.g1_group(cv)
+    g = (cv.g1[0], cv.g1[1], 1)
+    rng = random.Random(8)
+    for _ in range(4):
+        a, b = rng.randrange(cv.r), rng.randrange(cv.r)
+        pa = G.multiply(g, a)
+        assert pa[:2] == O.normalize(O.multiply(O.from_affine(ocv.g1), a, ocv), ocv) and pa[2] == 1
+        assert G.add(pa, G.multiply(g, b)) == G.multiply(g, (a + b) % cv.r)
+    assert G.add(g, G.neg(g)) == G.Z == (1, 1, 0)
+    assert G.add(g, g) == G.double(g) == G.multiply(g, 2)
+    assert G.multiply(g, 0) == G.Z and G.multiply(G.Z, 5) == G.Z and G.add(G.Z, g) == g
+    assert G.eq((g[0] * 4 % cv.p, g[1] * 4 % cv.p, 4), g)       # un-normalised input is accepted
+    G2 = C.g2_group(cv)
+    g2 = (cv.g2[0], cv.g2[1], (1, 0))
+    assert C.on_curve_g2(g2, cv) and G2.is_inf(G2.multiply(g2, cv.r))
+
+
+def test_kzg_constructor_and_attributes():
+    from kzg_snark_amd.kzg import KZG
+    with pytest.raises(ValueError, match="Unsupported curve type"):      # kzg.py:37
+        KZG("secp256k1")
+    k = KZG()                                                             # default bn254 (kzg.py:18)
+    assert k.curve_type == "bn254" and k.curve_order == O.BN254.r
+    assert k.G1 == (1, 2, 1) and k.Z1 == (1, 1, 0)
+    for attr in ("G1", "G2", "Z1", "Z2", "multiply", "add", "neg", "pairing", "eq", "curve_order", "Fq", "R", "X"):
+        assert hasattr(k, attr)                                           # kzg.py:40-54
+    assert k.X == k.R([0, 1]) and k.Fq(3) + 4 == 7
+    assert k.add(k.multiply(k.G1, 3), k.neg(k.G1)) == k.multiply(k.G1, 2)
+    kb = KZG("bls12_381")
+    assert kb.curve_order == O.BLS12_381.r and kb.G1[:2] == O.BLS12_381.g1
+
+
+def test_fft_ff_boundary_behaviour_without_gpu():
+    from kzg_snark_amd.fft_ff import fft_ff, ifft_ff, fft_ff_interpolation
+    F = GF(O.BLS12_381.r)
+    g = F.root_of_unity(8)
+    one = [F(9)]
+    assert fft_ff(one, g, F) is one                                       # fft_ff.py:16-17
+    assert ifft_ff(one, g, F) == one
+    with pytest.raises(AssertionError, match="power of 2"):               # fft_ff.py:74
+        fft_ff_interpolation([F(1)] * 6, g, F)
+    with pytest.raises(AssertionError, match="Order of g"):               # fft_ff.py:78
+        fft_ff_interpolation([F(1)] * 16, g, F)
+    with pytest.raises(ValueError):
+        fft_ff([F(1)] * 3, g, F)
+    with pytest.raises(ValueError):
+        fft_ff([1, 2], 3, GF(101))                                        # not a supported scalar field

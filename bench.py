@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X KZG engine (contract: see DESIGN.md section 6).
+
+One "step" = one pass of the hot path over one synthetic degree-2^20 polynomial on
+BLS12-381, inputs already resident in HBM:
+
+    INTT of 2^20 evaluations (what fft_ff_interpolation does, fft_ff.py:60-85)
+    followed by KZG.commit of the 2^20 coefficients against a 2^20-point SRS (kzg.py:80-120).
+
+`value` = commits/sec over the whole job (all ranks).  N > 1: one process per GPU, every
+rank commits its own polynomial against a replicated SRS -- the path shards by polynomial
+with no data-path collective, so scaling is "weak".
+
+Also reported on the same line: NTT Fr-elements/sec (the second half of BASELINE.json's
+metric), a roofline object for the dominant kernel (msm_accumulate, timed with HIP events
+on the library's stream inside the timed region), one for the NTT passes, and the CPU
+baseline (the oracle's C restatement of the reference algorithms, 1 core, bounded sample).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--curve bls12_381]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+R_BLS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def root_of_unity(r, gen, n):
+    return pow(gen, (r - 1) // n, r)
+
+
+def cpu_baseline(curve, log_n, r, omega):
+    """oracle/kzg_oracle.c (reference algorithms, single thread) on a bounded sample."""
+    from oracle import c_oracle as CO
+    n = 1 << log_n
+    rs = np.random.RandomState(123)
+    data = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    data[:, 3] >>= np.uint64(3)
+    t0 = time.perf_counter()
+    CO.fft(curve, data, omega, inverse=True)
+    t_ntt = time.perf_counter() - t0
+    sample = min(n, 1 << 13)
+    ck = CO.setup(curve, 0x1234567, 4)                      # any valid points; cost is per coefficient
+    ck = np.ascontiguousarray(np.tile(ck, (sample // 4, 1)))
+    t0 = time.perf_counter()
+    CO.commit(curve, ck, np.ascontiguousarray(data[:sample]))
+    t_commit_sample = time.perf_counter() - t0
+    t_commit_full = t_commit_sample * (n / sample)
+    return {
+        "value": 1.0 / (t_ntt + t_commit_full),
+        "unit": "commits/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"oracle/kzg_oracle.c, 1 thread: recursive INTT of 2^{log_n} measured in full ({t_ntt:.2f} s) + "
+                   f"naive double-and-add commit on a {sample}-coefficient slice ({t_commit_sample:.2f} s) scaled "
+                   f"linearly x{n // sample} to 2^{log_n} coefficients"),
+        "ntt_elements_per_s": n / t_ntt,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--curve", default="bls12_381")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from kzg_snark_amd import _native
+    ctx = _native.Context(args.curve, device=local_rank)
+    # a dedicated (non-null) torch stream shared with the library: torch copies and the
+    # library's kernels are then ordered on one queue
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
+
+    r, gen = (R_BLS, 7) if args.curve == "bls12_381" else (R_BN, 5)
+    fp_bytes = 48 if args.curve == "bls12_381" else 32
+    log_n = args.log_n
+    n = 1 << log_n
+    omega = root_of_unity(r, gen, n)
+    w_words = _native.int_to_words(omega)
+
+    # synthetic workload: SRS [tau^i G1] generated on the device; uniform Fr evaluations (seeded per rank)
+    tau = 0x6b7a675f736e61726b7a675f736e6172 % r
+    t0 = time.perf_counter()
+    srs = ctx.srs_generate(_native.int_to_words(tau), n)
+    ctx.synchronize()
+    t_srs = time.perf_counter() - t0
+    g = torch.Generator(device="cpu").manual_seed(0x6b7a + rank)
+    host = torch.randint(0, 1 << 62, (n, 4), generator=g, dtype=torch.int64)
+    host[:, 3] >>= 3                                       # < 2^253 < r
+    evals = host.to(dev)
+    work = torch.empty_like(evals)
+    lens = [n]
+
+    def step():
+        work.copy_(evals)                                   # the INTT is in place; keep the input resident
+        ctx.ntt_device(work.data_ptr(), log_n, w_words, True, 1)
+        return ctx.commit_device(srs, work.data_ptr(), lens, n)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        xy, inf = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    spans = {name: ctx.prof_read(name) for name in
+             ("ntt_pass", "msm_digits", "msm_sort", "msm_bounds", "msm_accumulate", "msm_finalize", "msm_reduce")}
+    if rank == 0:
+        acc_ms, acc_cnt = spans["msm_accumulate"]
+        acc_avg_s = (acc_ms / max(acc_cnt, 1)) * 1e-3
+        msm_bytes = n * (32 + 2 * fp_bytes)                 # scalars + affine points, per commit
+        ntt_ms, ntt_cnt = spans["ntt_pass"]
+        ntt_per_transform_s = (ntt_ms / max(ntt_cnt, 1)) * 2e-3 if log_n > 12 else (ntt_ms / max(ntt_cnt, 1)) * 1e-3
+        ntt_bytes = 2 * n * 32                              # read + write every element once
+        out = {
+            "metric": "KZG G1 commits/sec (INTT 2^%d + commit 2^%d, BLS12-381)" % (log_n, log_n)
+            if args.curve == "bls12_381" else "KZG G1 commits/sec (INTT + commit, BN254)",
+            "value": world * args.steps / elapsed,
+            "unit": "commits/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x14 limbs (381-bit Fp) / u32x9 limbs (255-bit Fr), integer",
+            "data": "synthetic",
+            "config": {"workload": f"degree-2^{log_n} INTT + KZG commit, {args.curve}, 2^{log_n}-point SRS, "
+                                   f"uniform Fr scalars, one polynomial per GPU per step",
+                       "log_n": log_n, "curve": args.curve, "window_bits": 16, "sharding": "one polynomial per rank"},
+            "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
+            "ntt_ms": ntt_per_transform_s * 1e3,
+            "kernel_ms_per_step": {k: (v[0] / args.steps) for k, v in spans.items()},
+            "srs_setup_s": t_srs,
+            "roofline": {
+                "kernel": "msm_accumulate_kernel",
+                "bound": "hbm",
+                "achieved": msm_bytes / acc_avg_s / 1e9 if acc_avg_s > 0 else None,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": (msm_bytes / acc_avg_s / 1e9) / HBM_PEAK_GBPS if acc_avg_s > 0 else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": msm_bytes,
+                "avg_launch_ms": acc_avg_s * 1e3,
+            },
+            "roofline_ntt": {
+                "kernel": "ntt_pass_kernel (2 launches per transform)",
+                "bound": "hbm",
+                "achieved": ntt_bytes / ntt_per_transform_s / 1e9 if ntt_per_transform_s > 0 else None,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": (ntt_bytes / ntt_per_transform_s / 1e9) / HBM_PEAK_GBPS if ntt_per_transform_s > 0 else None,
+                "traffic": None,
+                "algorithmic_bytes_per_transform": ntt_bytes,
+            },
+        }
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):                   # HBM bytes per launch from rocprofv3 --pmc passes
+            tr = json.load(open(traffic_file))
+            out["roofline"]["traffic"] = tr.get("msm_accumulate_kernel")
+            out["roofline_ntt"]["traffic"] = tr.get("ntt_pass_kernel_per_transform")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.curve, log_n, r, omega)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

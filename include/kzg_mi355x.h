@@ -88,6 +88,9 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t
 /* kzg_srs_generate builds [tau^i * G1], i = 0..n-1, on the device: the G1 half of KZG.setup
  * (kzg.py:70-72) with the secret supplied by the caller (the reference samples it at :67). */
 int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** out);
+/* The slice [tau^(start+i) * G1], i = 0..n-1: one rank's shard of a key partitioned by
+ * coefficient range across GPUs. */
+int kzg_srs_generate_range(kzg_ctx* ctx, const uint64_t tau[4], size_t start, size_t n, kzg_srs** out);
 /* Read points [start, start+count) back as canonical affine coordinates. */
 int kzg_srs_export(kzg_ctx* ctx, const kzg_srs* srs, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
 size_t kzg_srs_size(const kzg_srs* srs);

@@ -34,6 +34,7 @@ SIGNATURES = {
     "kzg_srs_free": (None, [_vp]),
     "kzg_srs_size": (ctypes.c_size_t, [_vp]),
     "kzg_srs_generate": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    "kzg_srs_generate_range": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "kzg_srs_export": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
@@ -164,9 +165,9 @@ class Context:
         self._check(lib().kzg_srs_load_g1(self._h, _as_vp(xy), _as_vp(inf), n, ctypes.byref(h)))
         return Srs(self, h, n)
 
-    def srs_generate(self, tau_words, n):
+    def srs_generate(self, tau_words, n, start=0):
         h = ctypes.c_void_p()
-        self._check(lib().kzg_srs_generate(self._h, _as_vp(tau_words), n, ctypes.byref(h)))
+        self._check(lib().kzg_srs_generate_range(self._h, _as_vp(tau_words), start, n, ctypes.byref(h)))
         return Srs(self, h, n)
 
     # ---- commit / open on host buffers

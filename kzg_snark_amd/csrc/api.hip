@@ -181,16 +181,20 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t
   return KZG_OK;
 }
 
-int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** out) {
+int kzg_srs_generate_range(kzg_ctx* ctx, const uint64_t tau[4], size_t start, size_t n, kzg_srs** out) {
   if (!ctx || !tau || !out) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;
   *out = nullptr;
   KZG_HIP(c, hipSetDevice(c->device));
   Srs* s = nullptr;
-  int rc = srs_generate(c, tau, n, &s);
+  int rc = srs_generate(c, tau, start, n, &s);
   if (rc) return rc;
   *out = new kzg_srs{s};
   return KZG_OK;
+}
+
+int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** out) {
+  return kzg_srs_generate_range(ctx, tau, 0, n, out);
 }
 
 int kzg_srs_export(kzg_ctx* ctx, const kzg_srs* srs, size_t start, size_t count, uint64_t* xy, uint8_t* inf) {

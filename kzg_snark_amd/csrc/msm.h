@@ -13,7 +13,7 @@ struct Srs {
 };
 
 int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out);
-int srs_generate(Ctx* c, const uint64_t* tau, size_t n, Srs** out);
+int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out);
 int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
 void srs_free(Srs* s);
 

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void gen_table_kernel(const uint32_t* g_rec, u
 // powers: canonical words of tau^i (computed by pow kernel below)
 template <class C>
 __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, const uint32_t* tau_mont,
-                                                           uint32_t* recs, size_t n) {
+                                                           uint32_t* recs, size_t start, size_t n) {
   using F = typename C::Fp;
   using Fr = typename C::Fr;
   using Fd = Field<F>;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, 
   Fe<Fr> b, acc = Frd::one();
 #pragma unroll
   for (int j = 0; j < Fr::N; ++j) b.l[j] = tau_mont[j];
-  for (size_t bits = i; bits; bits >>= 1) {
+  for (size_t bits = start + i; bits; bits >>= 1) {
     if (bits & 1u) acc = Frd::mul(acc, b);
     b = Frd::mul(b, b);
   }
@@ -439,7 +439,8 @@ static int srs_load_t(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, 
 }
 
 template <class C>
-static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t n, const uint64_t* gen_xy, Srs** out) {
+static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t start, size_t n, const uint64_t* gen_xy,
+                          Srs** out) {
   using F = typename C::Fp;
   using Fr = typename C::Fr;
   if (n == 0 || n * (size_t)NWIN >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_generate: bad size");
@@ -465,7 +466,7 @@ static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t n, const uin
                      (size_t)1, d_bad);
   hipLaunchKernelGGL(gen_table_kernel<C>, dim3(32), dim3(256), 0, c->stream, d_g, d_tab);
   hipLaunchKernelGGL(srs_generate_kernel<C>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, c->stream, d_tab, d_tau,
-                     s->recs, n);
+                     s->recs, start, n);
   e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(set_err(c, KZG_ERR_HIP, "srs generate", e));
   cleanup();
@@ -485,10 +486,10 @@ static const uint64_t GEN_BLS[12] = {
 int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
   return c->curve == 0 ? srs_load_t<Bn254>(c, xy, inf, n, out) : srs_load_t<Bls12_381>(c, xy, inf, n, out);
 }
-int srs_generate(Ctx* c, const uint64_t* tau, size_t n, Srs** out) {
+int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out) {
   const uint32_t* t = reinterpret_cast<const uint32_t*>(tau);
-  return c->curve == 0 ? srs_generate_t<Bn254>(c, t, n, GEN_BN254, out)
-                       : srs_generate_t<Bls12_381>(c, t, n, GEN_BLS, out);
+  return c->curve == 0 ? srs_generate_t<Bn254>(c, t, start, n, GEN_BN254, out)
+                       : srs_generate_t<Bls12_381>(c, t, start, n, GEN_BLS, out);
 }
 void srs_free(Srs* s) {
   if (!s) return;

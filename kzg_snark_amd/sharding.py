@@ -1,0 +1,74 @@
+"""Multi-GPU use of the engine: one process per GPU (torch.distributed; backend "nccl"
+is RCCL on ROCm, "gloo" in the CPU tests).  The reference has nothing distributed;
+this is the MI355X design of SURVEY.md section 8e:
+
+  * batch mode  -- the k polynomials of one commit call (3+1+3 per PLONK proof,
+    plonk/prover.py:89,113,136) are dealt round-robin to the ranks, each rank runs
+    whole MSMs against a replicated SRS, and the k result points (<= 97 bytes each)
+    are all-gathered.  No data-path collective.
+  * range mode  -- ONE polynomial and the SRS are partitioned by contiguous
+    coefficient range; every rank runs a full local Pippenger over its slice and the
+    G partial points are all-gathered and added on the host (the EC group law is not
+    an RCCL reduction operator): G-1 point additions, latency only.
+
+The local commit is injected (`commit_fn`) so the exchange logic is testable on CPU
+with gloo; in production it is KZG.commit on this rank's GPU."""
+import torch.distributed as dist
+
+
+def round_robin(n_items, world):
+    """owner rank of each item."""
+    return [i % world for i in range(n_items)]
+
+
+def range_of(rank, world, n):
+    """[lo, hi) coefficient range of `rank` when n coefficients are split in `world` contiguous blocks."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DistributedCommitter:
+    def __init__(self, commit_fn, add_fn, zero_point, group=None):
+        """commit_fn(list_of_coefficient_lists) -> list of points (this rank's device);
+        add_fn(p, q) -> point (host group law, e.g. KZG.add); zero_point: Z1."""
+        self.commit_fn = commit_fn
+        self.add_fn = add_fn
+        self.zero = zero_point
+        self.group = group
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def _all_gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def commit_batch(self, polynomials):
+        """Every rank passes the same list; returns the full ordered list of commitments on every rank."""
+        owners = round_robin(len(polynomials), self.world)
+        mine = [i for i, o in enumerate(owners) if o == self.rank]
+        local = self.commit_fn([polynomials[i] for i in mine]) if mine else []
+        gathered = self._all_gather(list(zip(mine, local)))
+        out = [None] * len(polynomials)
+        for part in gathered:
+            for i, pt in part:
+                out[i] = tuple(pt)
+        return out
+
+    def commit_range(self, local_coeffs):
+        """local_coeffs: this rank's contiguous slice of ONE polynomial (its SRS shard is what
+        commit_fn commits against).  Returns the commitment to the whole polynomial on every rank."""
+        part = self.commit_fn([local_coeffs])[0]
+        acc = self.zero
+        for pt in self._all_gather(tuple(part)):
+            acc = self.add_fn(acc, tuple(pt))
+        return acc

@@ -30,8 +30,9 @@ int set_err(Ctx* c, int code, const char* what, hipError_t e) {
   return code;
 }
 
-ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
+ProfScope::ProfScope(Ctx* ctx, const char* name, hipStream_t stream) : c(ctx) {
   if (!c->prof_on) return;
+  st = stream ? stream : c->stream;
   for (auto& sp : c->prof)
     if (sp.name == name) { span = &sp; break; }
   if (!span) {
@@ -40,11 +41,11 @@ ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
     span = &c->prof.back();
   }
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { span = nullptr; return; }
-  hipEventRecord(e0, c->stream);
+  hipEventRecord(e0, st);
 }
 ProfScope::~ProfScope() {
   if (!span) return;
-  hipEventRecord(e1, c->stream);
+  hipEventRecord(e1, st);
   span->pending.emplace_back(e0, e1);
 }
 
@@ -280,7 +281,7 @@ int kzg_prof_enable(kzg_ctx* ctx, int on) {
 int kzg_prof_reset(kzg_ctx* ctx) {
   if (!ctx) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;
-  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  KZG_HIP(c, hipDeviceSynchronize());
   for (auto& sp : c->prof) {
     for (auto& pr : sp.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     sp.pending.clear();
@@ -293,7 +294,7 @@ int kzg_prof_reset(kzg_ctx* ctx) {
 int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* count) {
   if (!ctx || !name || !total_ms || !count) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;
-  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  KZG_HIP(c, hipDeviceSynchronize());
   *total_ms = 0;
   *count = 0;
   for (auto& sp : c->prof) {

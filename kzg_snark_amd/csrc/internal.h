@@ -71,7 +71,8 @@ struct ProfScope {
   Ctx* c;
   ProfSpan* span = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  ProfScope(Ctx* ctx, const char* name);
+  hipStream_t st = nullptr;
+  ProfScope(Ctx* ctx, const char* name, hipStream_t stream = nullptr);
   ~ProfScope();
 };
 int ensure_buf(Ctx* c, DevBuf& b, size_t bytes);

@@ -519,11 +519,28 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
                        : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
 }
 
-// workspace for one in-flight commit
+// Commit pipeline.  Stage A (digits, sort, bounds, accumulate) runs on the context's stream;
+// stage B (finalize, bit-plane reduce, copy of the 16 T_b to pinned host memory) runs on an
+// auxiliary stream behind an event, so the latency-bound stage B of polynomial p overlaps the
+// ALU-bound stage A of polynomial p+1.  Stage-B buffers are double-buffered in two slots; the host
+// finishes a polynomial (Horner + one inversion) when its slot is recycled or at the end of the call.
+constexpr int NSLOT = 2;
+
+struct MsmSlot {
+  DevBuf slice_off, partials, buckets, bitpart, tb;
+  void* h_tb = nullptr;        // pinned host copy of the 16 T_b
+  hipEvent_t ev_a = nullptr;   // stage A done (partials, slice_off ready)
+  hipEvent_t ev_b = nullptr;   // stage B done (h_tb ready)
+  bool pending = false;
+  uint64_t* out_xy = nullptr;
+  uint8_t* out_inf = nullptr;
+};
+
 struct MsmWork {
-  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart, slice_off, partials, buckets, bitpart, tb;
-  void* h_tb = nullptr;       // pinned host copy of the 16 T_b
-  size_t cap_n = 0;
+  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart;    // stage A only
+  MsmSlot slot[NSLOT];
+  hipStream_t stream_b = nullptr;
+  int next = 0;
 };
 
 static MsmWork* get_work(Ctx* c) {
@@ -533,16 +550,20 @@ static MsmWork* get_work(Ctx* c) {
 void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
-  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart, &w->slice_off,
-                    &w->partials, &w->buckets, &w->bitpart, &w->tb})
-    hipFree(b->p);
-  if (w->h_tb) hipHostFree(w->h_tb);
+  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart}) hipFree(b->p);
+  for (auto& sl : w->slot) {
+    for (DevBuf* b : {&sl.slice_off, &sl.partials, &sl.buckets, &sl.bitpart, &sl.tb}) hipFree(b->p);
+    if (sl.h_tb) hipHostFree(sl.h_tb);
+    if (sl.ev_a) hipEventDestroy(sl.ev_a);
+    if (sl.ev_b) hipEventDestroy(sl.ev_b);
+  }
+  if (w->stream_b) hipStreamDestroy(w->stream_b);
   delete w;
   c->msm_work = nullptr;
 }
 
 template <class C>
-static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w) {
+static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, MsmSlot& sl) {
   constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
   const uint32_t m = n * NWIN;
   const uint32_t max_slices = m / SEG + NBUCKET + 1;
@@ -552,12 +573,15 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, w->vals_a, (size_t)m * 4))) return rc;
   if ((rc = ensure_buf(c, w->vals_b, (size_t)m * 4))) return rc;
   if ((rc = ensure_buf(c, w->bstart, (NBUCKET + 2) * 4))) return rc;
-  if ((rc = ensure_buf(c, w->slice_off, (NBUCKET + 2) * 4))) return rc;
-  if ((rc = ensure_buf(c, w->partials, (size_t)max_slices * PT))) return rc;
-  if ((rc = ensure_buf(c, w->buckets, (size_t)NBUCKET * PT))) return rc;
-  if ((rc = ensure_buf(c, w->bitpart, (size_t)15 * RED_WAVES * PT))) return rc;
-  if ((rc = ensure_buf(c, w->tb, (size_t)16 * PT))) return rc;
-  if (!w->h_tb) KZG_HIP(c, hipHostMalloc(&w->h_tb, 16 * 4 * 14 * 4));
+  if ((rc = ensure_buf(c, sl.slice_off, (NBUCKET + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.partials, (size_t)max_slices * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.buckets, (size_t)NBUCKET * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.bitpart, (size_t)15 * RED_WAVES * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.tb, (size_t)16 * PT))) return rc;
+  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, 16 * 4 * 14 * 4));
+  if (!sl.ev_a) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_a, hipEventDisableTiming));
+  if (!sl.ev_b) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_b, hipEventDisableTiming));
+  if (!w->stream_b) KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_b, hipStreamNonBlocking));
 
   auto* keys_a = static_cast<uint16_t*>(w->keys_a.p);
   auto* keys_b = static_cast<uint16_t*>(w->keys_b.p);
@@ -568,43 +592,51 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
                                        c->stream));
   if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
 
+  // ---- stage A on the context's stream
+  hipStream_t sa = c->stream, sb = w->stream_b;
   {
     ProfScope ps(c, "msm_digits");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_scalars, s->recs,
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, sa, d_scalars, s->recs,
                        (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
   }
   KZG_HIP(c, hipGetLastError());
   {
     ProfScope ps(c, "msm_sort");
     KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
-                                         c->stream));
+                                         sa));
   }
   auto* bstart = static_cast<uint32_t*>(w->bstart.p);
-  auto* slice_off = static_cast<uint32_t*>(w->slice_off.p);
+  auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
   {
     ProfScope ps(c, "msm_bounds");
-    hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, c->stream, keys_b, m, bstart);
-    hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, c->stream, bstart, slice_off);
+    hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, sa, keys_b, m, bstart);
+    hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, sa, bstart, slice_off);
   }
   {
     ProfScope ps(c, "msm_accumulate");
-    hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, c->stream, s->recs,
-                       vals_b, bstart, slice_off, static_cast<uint32_t*>(w->partials.p));
-  }
-  {
-    ProfScope ps(c, "msm_finalize");
-    hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, c->stream,
-                       static_cast<uint32_t*>(w->partials.p), slice_off, static_cast<uint32_t*>(w->buckets.p));
-  }
-  {
-    ProfScope ps(c, "msm_reduce");
-    hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, c->stream,
-                       static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->bitpart.p));
-    hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, c->stream, static_cast<uint32_t*>(w->bitpart.p),
-                       static_cast<uint32_t*>(w->buckets.p), static_cast<uint32_t*>(w->tb.p));
+    hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
+                       vals_b, bstart, slice_off, static_cast<uint32_t*>(sl.partials.p));
   }
   KZG_HIP(c, hipGetLastError());
-  KZG_HIP(c, hipMemcpyAsync(w->h_tb, w->tb.p, 16 * PT, hipMemcpyDeviceToHost, c->stream));
+  KZG_HIP(c, hipEventRecord(sl.ev_a, sa));
+
+  // ---- stage B on the auxiliary stream
+  KZG_HIP(c, hipStreamWaitEvent(sb, sl.ev_a, 0));
+  {
+    ProfScope ps(c, "msm_finalize", sb);
+    hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, sb,
+                       static_cast<uint32_t*>(sl.partials.p), slice_off, static_cast<uint32_t*>(sl.buckets.p));
+  }
+  {
+    ProfScope ps(c, "msm_reduce", sb);
+    hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, sb,
+                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.bitpart.p));
+    hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, sb, static_cast<uint32_t*>(sl.bitpart.p),
+                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.tb.p));
+  }
+  KZG_HIP(c, hipGetLastError());
+  KZG_HIP(c, hipMemcpyAsync(sl.h_tb, sl.tb.p, 16 * PT, hipMemcpyDeviceToHost, sb));
+  KZG_HIP(c, hipEventRecord(sl.ev_b, sb));
   return KZG_OK;
 }
 
@@ -638,6 +670,15 @@ static void msm_finish_host(const void* h_tb, uint64_t* out_xy, uint8_t* out_inf
 }
 
 template <class C>
+static int msm_retire(Ctx* c, MsmSlot& sl) {
+  if (!sl.pending) return KZG_OK;
+  KZG_HIP(c, hipEventSynchronize(sl.ev_b));
+  msm_finish_host<C>(sl.h_tb, sl.out_xy, sl.out_inf);
+  sl.pending = false;
+  return KZG_OK;
+}
+
+template <class C>
 static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
                     size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
   using F = typename C::Fp;
@@ -646,19 +687,29 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     if (lens[p] > s->n) return set_err(c, KZG_ERR_DEGREE, "polynomial longer than the commitment key");
     if (lens[p] > stride) return set_err(c, KZG_ERR_ARG, "kzg_commit: lens[p] > stride");
   }
-  for (size_t p = 0; p < n_polys; ++p) {
+  int rc = KZG_OK;
+  for (size_t p = 0; p < n_polys && rc == KZG_OK; ++p) {
     uint64_t* o = out_xy + p * 2 * (F::NW / 2);
     if (lens[p] == 0) {   // zero polynomial: Z1 (kzg.py:109)
       memset(o, 0, 2 * F::NW * 4);
       out_inf[p] = 1;
       continue;
     }
-    int rc = msm_enqueue<C>(c, s, d_scalars + p * stride * 8, (uint32_t)lens[p], w);
-    if (rc) return rc;
-    KZG_HIP(c, hipStreamSynchronize(c->stream));
-    msm_finish_host<C>(w->h_tb, o, out_inf + p);
+    MsmSlot& sl = w->slot[w->next];
+    w->next = (w->next + 1) % NSLOT;
+    if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
+    if ((rc = msm_enqueue<C>(c, s, d_scalars + p * stride * 8, (uint32_t)lens[p], w, sl))) break;
+    sl.pending = true;
+    sl.out_xy = o;
+    sl.out_inf = out_inf + p;
   }
-  return KZG_OK;
+  for (int k = 0; k < NSLOT; ++k) {               // drain in issue order
+    MsmSlot& sl = w->slot[(w->next + k) % NSLOT];
+    int r2 = msm_retire<C>(c, sl);
+    if (rc == KZG_OK) rc = r2;
+  }
+  if (rc == KZG_OK) KZG_HIP(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,

@@ -98,7 +98,7 @@ struct Ec {
     const E Q = Fd::mul(a.x, PP);
     P r;
     r.x = Fd::sub(Fd::sub(Fd::sqr(R), PPP), Fd::dbl(Q));
-    r.y = Fd::sub(Fd::mul(R, Fd::sub(Q, r.x)), Fd::mul(a.y, PPP));
+    r.y = Fd::mul2(R, Fd::sub(Q, r.x), Fd::neg(a.y), PPP);     // R*(Q - X3) - Y1*PPP, one reduction
     r.zz = Fd::mul(a.zz, PP);
     r.zzz = Fd::mul(a.zzz, PPP);
     return r;
@@ -122,7 +122,7 @@ struct Ec {
     const E Q = Fd::mul(U1, PP);
     P r;
     r.x = Fd::sub(Fd::sub(Fd::sqr(R), PPP), Fd::dbl(Q));
-    r.y = Fd::sub(Fd::mul(R, Fd::sub(Q, r.x)), Fd::mul(S1, PPP));
+    r.y = Fd::mul2(R, Fd::sub(Q, r.x), Fd::neg(S1), PPP);
     r.zz = Fd::mul(Fd::mul(a.zz, b.zz), PP);
     r.zzz = Fd::mul(Fd::mul(a.zzz, b.zzz), PPP);
     return r;

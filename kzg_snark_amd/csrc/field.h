@@ -138,7 +138,74 @@ struct Field {
     r.l[N - 1] = (uint32_t)(w[N - 1] + c);
     return r;
   }
-  static KZG_HD E sqr(const E& a) { return mul(a, a); }
+  // Montgomery square: the off-diagonal products are computed once against the doubled
+  // operand (N(N+1)/2 + N^2 multiply-adds instead of 2N^2).  Input limbs < 2^29.
+  static KZG_HD E sqr(const E& a) {
+    uint64_t t[2 * N];
+    uint32_t a2[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) a2[j] = a.l[j] << 1;
+#pragma unroll
+    for (int k = 0; k < 2 * N; ++k) t[k] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      t[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) t[i + j] += (uint64_t)a.l[i] * a2[j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t m = ((uint32_t)t[i] * F::N0) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; ++j) t[i + j] += (uint64_t)m * F::P[j];
+      t[i + 1] += t[i] >> L;
+    }
+    E r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint64_t v = t[N + j] + c;
+      r.l[j] = (uint32_t)v & MASK;
+      c = v >> L;
+    }
+    r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
+    return r;
+  }
+
+  // a*b + c*d with ONE Montgomery reduction (weak-normal in and out: (4p^2+4p^2)/R + p < 2p
+  // needs 8p < R, true for all four fields).  Columns hold 2N products + N reduction products.
+  static KZG_HD E mul2(const E& a, const E& b, const E& c, const E& d) {
+    static_assert(F::BITS + 3 <= L * N, "mul2 needs 8p < R");
+    uint64_t w[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) w[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t bi = b.l[i], di = d.l[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) w[j] += (uint64_t)a.l[j] * bi;
+#pragma unroll
+      for (int j = 0; j < N; ++j) w[j] += (uint64_t)c.l[j] * di;
+      const uint32_t m = ((uint32_t)w[0] * F::N0) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; ++j) w[j] += (uint64_t)m * F::P[j];
+      const uint64_t cy = w[0] >> L;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
+      w[N - 1] = 0;
+      w[0] += cy;
+    }
+    E r;
+    uint64_t cy = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint64_t t = w[j] + cy;
+      r.l[j] = (uint32_t)t & MASK;
+      cy = t >> L;
+    }
+    r.l[N - 1] = (uint32_t)(w[N - 1] + cy);
+    return r;
+  }
 
   // a + b, weak-normal in and out
   static KZG_HD E add(const E& a, const E& b) {

@@ -23,6 +23,9 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
       R = Fd::sub(Fd::mul(Fd::add(Fd::mul(s, d), A), B), Fd::neg(B));
       break;
     }
+    case 7: R = Fd::sqr(A); break;
+    case 8: R = Fd::mul2(A, B, Fd::add(A, B), Fd::sub(B, A)); break;   // a*b + (a+b)*(b-a)
+    case 9: R = Fd::sqr(Fd::sub(A, B)); break;
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);

@@ -36,7 +36,9 @@ def test_field_ops(shim, fid, p, nw):
     rng = random.Random(fid)
     ops = [(0, lambda a, b: a * b % p), (1, lambda a, b: (a + b) % p), (2, lambda a, b: (a - b) % p),
            (4, lambda a, b: (-a) % p), (5, lambda a, b: 2 * a % p),
-           (6, lambda a, b: ((((a + b) * (a - b) + a) * b) + b) % p)]
+           (6, lambda a, b: ((((a + b) * (a - b) + a) * b) + b) % p),
+           (7, lambda a, b: a * a % p), (8, lambda a, b: (a * b + (a + b) * (b - a)) % p),
+           (9, lambda a, b: (a - b) * (a - b) % p)]
     for _ in range(1500):
         a = rng.choice([0, 1, 2, p - 1, p - 2, rng.randrange(p), rng.randrange(p), 1 << (p.bit_length() - 1)])
         b = rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)])

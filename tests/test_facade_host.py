@@ -94,3 +94,75 @@ def test_fft_ff_boundary_behaviour_without_gpu():
         fft_ff([F(1)] * 3, g, F)
     with pytest.raises(ValueError):
         fft_ff([1, 2], 3, GF(101))                                        # not a supported scalar field
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_pairing_bilinear(name):
+    from kzg_snark_amd.pairing import pairing
+    cv = C.CURVES[name]
+    G1, G2 = C.g1_group(cv), C.g2_group(cv)
+    g1, g2 = (cv.g1[0], cv.g1[1], 1), (cv.g2[0], cv.g2[1], (1, 0))
+    e = pairing(g2, g1, cv)
+    assert pairing(G2.multiply(g2, 6), G1.multiply(g1, 35), cv) == pairing(G2.multiply(g2, 210), g1, cv)
+    assert pairing(g2, G1.multiply(g1, 210), cv) == pairing(G2.multiply(g2, 30), G1.multiply(g1, 7), cv)
+    assert pairing(g2, G1.Z, cv) == pairing(G2.Z, g1, cv) != e          # e(O, Q) = e(P, O) = 1
+    assert pairing(g2, G1.neg(g1), cv) != e
+
+
+@pytest.mark.parametrize("name", ["bn254", "bls12_381"])
+def test_check_and_batch_check_with_trapdoor_commitments(name):
+    """KZG.check / batch_check (kzg.py:161-288) on commitments built from the trapdoor
+    (commit(p) = p(tau) G1), so no GPU is needed; tampering must be rejected (kzg.py:361-380)."""
+    from kzg_snark_amd.kzg import KZG
+    kzg = KZG(name)
+    Fq, r = kzg.Fq, kzg.curve_order
+    rng = random.Random(17)
+    tau = rng.randrange(r)
+    rk = kzg.multiply(kzg.G2, tau)
+
+    def ev(p, x):
+        acc = 0
+        for c in reversed(p):
+            acc = (acc * x + c) % r
+        return acc
+
+    def instance(polys):
+        z, xi = rng.randrange(r), rng.randrange(r)
+        comms = [kzg.multiply(kzg.G1, ev(p, tau)) for p in polys]
+        evals = [ev(p, z) for p in polys]
+        comb_tau = sum(pow(xi, i + 1, r) * ev(p, tau) for i, p in enumerate(polys)) % r
+        comb_z = sum(pow(xi, i + 1, r) * e for i, e in enumerate(evals)) % r
+        proof = kzg.multiply(kzg.G1, (comb_tau - comb_z) * pow((tau - z) % r, -1, r) % r)
+        return comms, z, evals, proof, xi
+
+    insts = [instance([[rng.randrange(r) for _ in range(4)] for _ in range(2)]) for _ in range(3)]
+    for comms, z, evals, proof, xi in insts:
+        assert kzg.check(rk, comms, z, evals, proof, xi)
+    args = [list(t) for t in zip(*insts)]
+    assert kzg.batch_check(rk, *args)
+    assert kzg.batch_check(rk, *args, r=Fq(12345))
+    bad = [list(e) for e in args[2]]
+    bad[0][0] = (bad[0][0] + 1) % r
+    assert not kzg.check(rk, insts[0][0], insts[0][1], bad[0], insts[0][3], insts[0][4])
+    assert not kzg.batch_check(rk, args[0], args[1], bad, args[3], args[4])
+
+
+def test_transcript_bytes():
+    import hashlib
+    import struct
+    from kzg_snark_amd.transcript import Transcript
+    F = GF(O.BN254.r)
+    t = Transcript("plonk-proof", F)
+    s0 = hashlib.sha256(b"plonk-proof").digest()
+    assert t.state == s0
+    pt = (1, 2, 1)
+    t.append_message("round1", [pt, 7, "x", F(5)])
+    ser = str(pt).encode() + struct.pack(">q", 7) + b"x" + b"5"
+    s1 = hashlib.sha256(s0 + b"round1" + ser).digest()
+    assert t.state == s1
+    c = t.get_challenge("beta")
+    h = hashlib.sha256(s1 + b"beta").digest()
+    assert int(c) == int.from_bytes(h, "big") % O.BN254.r
+    assert t.state == hashlib.sha256(s1 + b"beta" + h).digest()
+    with pytest.raises(struct.error):
+        t.append_message("big", 1 << 70)          # the reference's ">q" packing has the same limit

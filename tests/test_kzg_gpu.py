@@ -194,3 +194,29 @@ def test_commit_full_size_2_20_trapdoor(native, kzgs):
     want = O.normalize(O.open_trapdoor([coeffs], z, xi, tau, cv), cv)
     assert (got[0], got[1]) == want
     assert native.limbs_to_ints(ev.reshape(1, 4))[0] == xi * O.poly_eval(coeffs, z, cv.r) % cv.r
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_reference_selftest_recipe(kzgs, curve):
+    """The reference's only test of this path, kzg.py:291-380, replayed on the engine:
+    setup(5); three lists of two polynomials; commit, open, check per list, batch_check,
+    batch == all(individual); then a corrupted evaluation must be rejected by both."""
+    kzg = kzgs[curve]
+    Fq = kzg.Fq
+    ck, rk = kzg.setup(5)                                   # unseeded tau, as in the reference
+    lists = [[[1, 2, 3, 4, 5], [5, 4, 3, 2, 1]],
+             [[2, 0, 1], [0, 0, 0, 7]],
+             [[9, 8, 7, 6, 5, 4], [1]]]
+    commitments_list = [kzg.commit(ck, polys) for polys in lists]
+    z_list = [Fq.random_element() for _ in lists]
+    xi_list = [Fq.random_element() for _ in lists]
+    evaluations_list = [[kzg.R(p)(z) for p in polys] for polys, z in zip(lists, z_list)]
+    proof_list = [kzg.open(ck, polys, z, xi) for polys, z, xi in zip(lists, z_list, xi_list)]
+    individual = [kzg.check(rk, c, z, e, p, xi)
+                  for c, z, e, p, xi in zip(commitments_list, z_list, evaluations_list, proof_list, xi_list)]
+    assert all(individual)
+    assert kzg.batch_check(rk, commitments_list, z_list, evaluations_list, proof_list, xi_list)
+    bad = [list(e) for e in evaluations_list]
+    bad[1][0] = bad[1][0] + 1
+    assert not kzg.check(rk, commitments_list[1], z_list[1], bad[1], proof_list[1], xi_list[1])
+    assert not kzg.batch_check(rk, commitments_list, z_list, bad, proof_list, xi_list)

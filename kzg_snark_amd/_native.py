@@ -38,6 +38,8 @@ SIGNATURES = {
     "kzg_srs_export": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "kzg_commit_device_async": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
+    "kzg_commit_flush": (ctypes.c_int, [_vp]),
     "kzg_open": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "kzg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "kzg_prof_reset": (ctypes.c_int, [_vp]),
@@ -189,6 +191,16 @@ class Context:
         self._check(lib().kzg_commit_device(self._h, srs._h, _as_vp(d_scalars), _as_vp(lens_a), n_polys,
                                             stride, _as_vp(out_xy), _as_vp(out_inf)))
         return out_xy, out_inf
+
+    def commit_device_async(self, srs, d_scalars, lens, stride, out_xy, out_inf):
+        """Pipelined commit: results land in the caller's out_xy / out_inf (numpy, kept alive by the
+        caller) by the time commit_flush() returns."""
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        self._check(lib().kzg_commit_device_async(self._h, srs._h, _as_vp(d_scalars), _as_vp(lens_a), len(lens),
+                                                  stride, _as_vp(out_xy), _as_vp(out_inf)))
+
+    def commit_flush(self):
+        self._check(lib().kzg_commit_flush(self._h))
 
     def open(self, srs, polys, lens, stride, z_words, xi_words, device=False):
         k = len(lens)

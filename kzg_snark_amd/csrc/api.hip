@@ -221,6 +221,22 @@ int kzg_commit_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, c
   return commit_device(c, srs->s, static_cast<const uint32_t*>(d_scalars), lens, n_polys, stride, out_xy, out_inf);
 }
 
+int kzg_commit_device_async(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, const size_t* lens,
+                            size_t n_polys, size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+  if (!ctx || !srs || !lens || !out_xy || !out_inf || (n_polys && !d_scalars)) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return commit_device(c, srs->s, static_cast<const uint32_t*>(d_scalars), lens, n_polys, stride, out_xy, out_inf,
+                       false);
+}
+
+int kzg_commit_flush(kzg_ctx* ctx) {
+  if (!ctx) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return commit_flush(c);
+}
+
 int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const size_t* lens, size_t n_polys,
                size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
   if (!ctx || !srs || !lens || !out_xy || !out_inf || (n_polys && stride && !scalars)) return KZG_ERR_ARG;

@@ -679,8 +679,21 @@ static int msm_retire(Ctx* c, MsmSlot& sl) {
 }
 
 template <class C>
+static int commit_flush_t(Ctx* c) {
+  MsmWork* w = get_work(c);
+  int rc = KZG_OK;
+  for (int k = 0; k < NSLOT; ++k) {               // drain in issue order
+    MsmSlot& sl = w->slot[(w->next + k) % NSLOT];
+    int r2 = msm_retire<C>(c, sl);
+    if (rc == KZG_OK) rc = r2;
+  }
+  if (rc == KZG_OK) KZG_HIP(c, hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+template <class C>
 static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
-                    size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+                    size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain) {
   using F = typename C::Fp;
   MsmWork* w = get_work(c);
   for (size_t p = 0; p < n_polys; ++p) {
@@ -703,20 +716,20 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     sl.out_xy = o;
     sl.out_inf = out_inf + p;
   }
-  for (int k = 0; k < NSLOT; ++k) {               // drain in issue order
-    MsmSlot& sl = w->slot[(w->next + k) % NSLOT];
-    int r2 = msm_retire<C>(c, sl);
+  if (drain || rc != KZG_OK) {
+    int r2 = commit_flush_t<C>(c);
     if (rc == KZG_OK) rc = r2;
   }
-  if (rc == KZG_OK) KZG_HIP(c, hipStreamSynchronize(c->stream));
   return rc;
 }
 
+int commit_flush(Ctx* c) { return c->curve == 0 ? commit_flush_t<Bn254>(c) : commit_flush_t<Bls12_381>(c); }
+
 int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
-                  size_t stride, uint64_t* out_xy, uint8_t* out_inf) {
+                  size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain) {
   if (s->curve != c->curve) return set_err(c, KZG_ERR_ARG, "SRS belongs to another curve");
-  return c->curve == 0 ? commit_t<Bn254>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf)
-                       : commit_t<Bls12_381>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf);
+  return c->curve == 0 ? commit_t<Bn254>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain)
+                       : commit_t<Bls12_381>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain);
 }
 
 }  // namespace kzg

@@ -3,7 +3,7 @@
 //
 // Representation ("unsaturated limbs"): an element is N limbs of L bits held in
 // 32-bit words, value = sum l[j] * 2^(L*j).  L = 29 (N = 9) for the ~255-bit
-// fields, L = 28 (N = 14) for the 381-bit BLS12-381 base field.  The point of the
+// fields, L = 30 (N = 13) for the 381-bit BLS12-381 base field.  The point of the
 // slack bits is the multiplier: on gfx950 a 32x32+64 multiply-add
 // (v_mad_u64_u32) issues at the same rate as an FP64 FMA (measured,
 // tools/microbench/int_rates.hip) but has no carry-in, so with saturated
@@ -20,9 +20,11 @@
 // Montgomery radix R = 2^(L*N); 4p < R for all four fields, so mul() maps
 // weak-normal inputs to a weak-normal output:  (ab + mp)/R < 4p^2/R + p < 2p.
 //
-// Bound for mul(): inputs may have limbs up to 2^30 (sums of unnormalised
-// values): a column receives at most N products a_j*b_i < 2^60 and N products
-// m*p_j < 2^(2L) plus a carry < 2^37, i.e. < 14*2^60 + 14*2^56 + 2^37 < 2^64.
+// Column bound: a 64-bit column absorbs CAP = 2^(64-2L) - 1 products of two L-bit
+// limbs.  A Montgomery row adds two products per column (a_j*b_i and m*p_j), so
+// the sliding window is carry-normalised every CAP/2 rows: never for L = 29, N = 9
+// (CAP = 63), once (after row 7) for L = 30, N = 13 (CAP = 15).  Inputs must have
+// normalised limbs (< 2^L), which every function of this header guarantees.
 #pragma once
 #include <stdint.h>
 #include "curve_constants.h"
@@ -47,7 +49,21 @@ struct Field {
   static constexpr int N = F::N;
   static constexpr int NW = F::NW;
   static constexpr uint32_t MASK = F::MASK;
+  // products of two normalised limbs that fit one 64-bit column (with room for carries)
+  static constexpr int CAP = (2 * L >= 64) ? 0 : (int)((1ull << (64 - 2 * L)) - 1);
+  static_assert(CAP >= 15, "limb width too large for 64-bit columns");
   using E = Fe<F>;
+
+  // carry-normalise a window of 64-bit columns in place (value unchanged)
+  template <int M>
+  static KZG_HD void normalize_cols(uint64_t (&w)[M]) {
+#pragma unroll
+    for (int j = 0; j < M - 1; ++j) {
+      const uint64_t c = w[j] >> L;
+      w[j] &= (uint64_t)MASK;
+      w[j + 1] += c;
+    }
+  }
 
   static KZG_HD E zero() {
     E r;
@@ -126,6 +142,8 @@ struct Field {
       for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
       w[N - 1] = 0;
       w[0] += c;
+      constexpr int ROWS = CAP / 2;
+      if (ROWS < N && (i + 1) % ROWS == 0 && i + 1 < N) normalize_cols(w);
     }
     E r;
     uint64_t c = 0;
@@ -139,7 +157,7 @@ struct Field {
     return r;
   }
   // Montgomery square: the off-diagonal products are computed once against the doubled
-  // operand (N(N+1)/2 + N^2 multiply-adds instead of 2N^2).  Input limbs < 2^29.
+  // operand (N(N+1)/2 + N^2 multiply-adds instead of 2N^2).
   static KZG_HD E sqr(const E& a) {
     uint64_t t[2 * N];
     uint32_t a2[N];
@@ -153,6 +171,9 @@ struct Field {
 #pragma unroll
       for (int j = i + 1; j < N; ++j) t[i + j] += (uint64_t)a.l[i] * a2[j];
     }
+    // product columns hold up to N product-equivalents (doubled terms count twice); the
+    // reduction adds up to N more
+    if (2 * N > CAP) normalize_cols(t);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const uint32_t m = ((uint32_t)t[i] * F::N0) & MASK;
@@ -194,6 +215,8 @@ struct Field {
       for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
       w[N - 1] = 0;
       w[0] += cy;
+      constexpr int ROWS = CAP / 3;          // three products per column per row
+      if (ROWS < N && (i + 1) % ROWS == 0 && i + 1 < N) normalize_cols(w);
     }
     E r;
     uint64_t cy = 0;

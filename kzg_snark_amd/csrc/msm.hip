@@ -53,11 +53,12 @@ __device__ __forceinline__ void load_rec(const uint32_t* recs, size_t idx, Fe<ty
                                          Fe<typename C::Fp>& y) {
   constexpr int N = C::Fp::N;
   const uint32_t* p = recs + idx * Rec<C>::WORDS;
-  uint32_t w[2 * N];
-  if constexpr ((2 * N) % 4 == 0) {
+  constexpr int Q = (2 * N + 3) / 4;                 // 16-byte loads covering x and y
+  uint32_t w[4 * Q];
+  if constexpr (4 * Q <= Rec<C>::WORDS && (Rec<C>::WORDS % 4) == 0) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
 #pragma unroll
-    for (int i = 0; i < (2 * N) / 4; ++i) {
+    for (int i = 0; i < Q; ++i) {
       const uint4 v = q[i];
       w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
     }
@@ -578,7 +579,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.buckets, (size_t)NBUCKET * PT))) return rc;
   if ((rc = ensure_buf(c, sl.bitpart, (size_t)15 * RED_WAVES * PT))) return rc;
   if ((rc = ensure_buf(c, sl.tb, (size_t)16 * PT))) return rc;
-  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, 16 * 4 * 14 * 4));
+  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, 16 * 4 * 16 * 4));
   if (!sl.ev_a) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_a, hipEventDisableTiming));
   if (!sl.ev_b) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_b, hipEventDisableTiming));
   if (!w->stream_b) KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_b, hipStreamNonBlocking));

@@ -9,7 +9,9 @@ namespace kzg {
 struct Srs {
   size_t n = 0;
   int curve = 0;
-  uint32_t* recs = nullptr;   // [NWIN][n] records of Curve::REC_WORDS words
+  int win_bits = 16;          // Pippenger window c: 20 for keys of >= 2^18 points, else 16
+  int nwin = 16;              // ceil(256 / c) table windows
+  uint32_t* recs = nullptr;   // [nwin][n] records of Curve::REC_WORDS words
 };
 
 int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out);

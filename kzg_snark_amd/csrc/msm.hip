@@ -9,22 +9,26 @@
 //     128-byte record each (BLS12-381; one cache line per gather).  With the
 //     multiples precomputed ALL windows feed ONE set of 2^(c-1) buckets: no
 //     per-window bucket sets, no doublings between windows at commit time.
-//   commit:
+//     c = 20 (13 windows, 2^19 buckets) for keys of >= 2^18 points, else c = 16.
+//   commit, stage A (the context's stream):
 //     1 digits      scalar -> W signed c-bit digits; entry (bucket |d|-1, table
 //                   index j*n+i, sign)                       [kzg.py:113-114 zero skip]
-//     2 sort        entries by bucket (rocPRIM radix sort on 16-bit keys)
-//     3 bounds      first entry of every bucket (binary search), slices per bucket, scan
-//     4 accumulate  one thread per slice of <= SEG entries of one bucket: gathers
-//                   records and runs mixed XYZZ additions      <- the dominant kernel
-//     5 finalize    8 lanes per bucket fold the slice partials
-//     6 reduce      sum_k k*B_k = sum_b 2^b * T_b with T_b = sum of buckets whose
-//                   index has bit b set: 15 parallel tree sums, wave shuffles
-//     7 host        Horner over the 16 T_b, one inversion to affine (O(1) work)
-//
-// c = 16: 16 digits for scalars < 2^255 (top digit cannot wrap since r < 2^255).
+//     2 sort        entries by bucket (rocPRIM radix sort)
+//     3 bounds      first entry of every bucket; buckets ordered by length (so the
+//                   lanes of a wave run equal trip counts); slices of <= SEG entries
+//     4 accumulate  one thread per slice: gathers records and runs mixed XYZZ
+//                   additions                                 <- the dominant kernel
+//   stage B (auxiliary stream, overlaps stage A of the next polynomial):
+//     5 finalize    a few lanes per bucket fold slice partials (most buckets: one)
+//     6 reduce      sum_v v*B_v with v = hi*2^LO + lo:  2^LO * sum_hi hi*R_hi +
+//                   sum_lo lo*C_lo from row sums R and column sums C of the bucket
+//                   matrix (2 additions per bucket, tree-shaped), then bit-plane
+//                   sums of the short R and C vectors
+//     7 host        Horner over the ~20 partial points, one inversion to affine
 #include <cstring>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include "internal.h"
 #include "ec.h"
 #include "msm.h"
@@ -34,13 +38,21 @@ namespace kzg {
 
 namespace {
 
-constexpr int WIN_BITS = 16;
-constexpr int NWIN = 16;
-constexpr uint32_t NBUCKET = 1u << (WIN_BITS - 1);   // bucket k holds digit magnitude k+1
-constexpr uint32_t SEG = 32;                          // max entries per accumulate thread
-constexpr uint32_t FIN_LANES = 8;                     // lanes per bucket in finalize
-constexpr uint32_t RED_PER_LANE = 4;                  // buckets per lane in reduce stage 1
-constexpr uint32_t RED_WAVES = (NBUCKET / 2) / (64 * RED_PER_LANE);   // 64 partials per bit
+// Window configuration.  Scalars are < 2^255, so the top digit never wraps.
+template <int WB>
+struct Win {
+  static constexpr int BITS = WB;
+  static constexpr int NWIN = (256 + WB - 1) / WB;            // 16 -> 16 windows, 20 -> 13
+  static constexpr uint32_t NB = 1u << (WB - 1);              // bucket k holds digit magnitude k+1
+  static constexpr uint32_t SEG = WB >= 20 ? 64 : 32;         // max entries per accumulate thread
+  static constexpr uint32_t FIN = WB >= 20 ? 2 : 8;           // lanes per bucket in finalize
+  static constexpr int LO = WB / 2;                           // bucket matrix: 2^HI rows x 2^LO columns
+  static constexpr int HI = WB - 1 - LO;
+  static constexpr int NPART = HI + LO + 1;                   // points handed to the host
+  using Key = typename std::conditional<(WB <= 16), uint16_t, uint32_t>::type;
+  static constexpr Key SKIP = (Key)((1u << WB) - 1);          // sorts behind every bucket
+};
+constexpr int MAX_NPART = 24;
 
 template <class C> struct Rec {
   static constexpr int WORDS = C::REC_WORDS;
@@ -139,9 +151,9 @@ __global__ void srs_import_kernel(const uint32_t* xy, const uint8_t* inf, uint32
   store_rec<C>(recs, i, x, y, is_inf);
 }
 
-// records of window j -> window j+1: multiply every point by 2^WIN_BITS
+// records of window j -> window j+1: multiply every point by 2^win_bits
 template <class C>
-__global__ __launch_bounds__(128) void srs_window_kernel(const uint32_t* src, uint32_t* dst, size_t n) {
+__global__ __launch_bounds__(128) void srs_window_kernel(const uint32_t* src, uint32_t* dst, size_t n, int win_bits) {
   using F = typename C::Fp;
   using Fd = Field<F>;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(128) void srs_window_kernel(const uint32_t* src, ui
   load_rec<C>(src, i, x, y);
   const bool is_inf = src[i * Rec<C>::WORDS + Rec<C>::FLAG] & 1u;
   XYZZ<C> p = is_inf ? Ec<C>::infinity() : Ec<C>::dbl_affine(x, y);
-  for (int d = 1; d < WIN_BITS; ++d) p = Ec<C>::dbl(p);
+  for (int d = 1; d < win_bits; ++d) p = Ec<C>::dbl(p);
   const Affine<C> a = Ec<C>::to_affine(p);
   store_rec<C>(dst, i, Fd::reduce(a.x), Fd::reduce(a.y), a.inf);
 }
@@ -236,31 +248,37 @@ __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, 
 // ---- commit pipeline ----------------------------------------------------------------
 
 // scalar i -> NWIN signed digits; entry e = j*n + i
+template <int WB>
 __global__ void msm_digits_kernel(const uint32_t* scalars, const uint32_t* recs_flags_base, uint32_t rec_words,
-                                  uint32_t flag_word, uint32_t n, uint32_t srs_n, uint16_t* keys,
+                                  uint32_t flag_word, uint32_t n, uint32_t srs_n, typename Win<WB>::Key* keys,
                                   uint32_t* vals) {
+  using W = Win<WB>;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  const uint4 lo = sp[0], hi = sp[1];
-  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const uint4 lo4 = sp[0], hi4 = sp[1];
+  const uint32_t w[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
   const bool pt_inf = recs_flags_base[(size_t)i * rec_words + flag_word] & 1u;
   uint32_t carry = 0;
 #pragma unroll
-  for (int j = 0; j < NWIN; ++j) {
-    uint32_t d = ((w[j >> 1] >> (16 * (j & 1))) & 0xffffu) + carry;
+  for (int j = 0; j < W::NWIN; ++j) {
+    const int bit = j * WB, k = bit >> 5, sh = bit & 31;
+    const uint64_t two = ((uint64_t)w[k + 1] << 32) | w[k];
+    uint32_t d = ((uint32_t)(two >> sh) & ((1u << WB) - 1)) + carry;
     uint32_t neg = 0;
-    if (d > (1u << (WIN_BITS - 1))) { d = (1u << WIN_BITS) - d; neg = 1; carry = 1; } else { carry = 0; }
+    if (d > (1u << (WB - 1))) { d = (1u << WB) - d; neg = 1; carry = 1; } else { carry = 0; }
     const bool skip = (d == 0) || pt_inf;           // zero digit / infinity point contribute nothing
-    keys[(size_t)j * n + i] = skip ? (uint16_t)0xffff : (uint16_t)(d - 1);
+    keys[(size_t)j * n + i] = skip ? W::SKIP : (typename W::Key)(d - 1);
     vals[(size_t)j * n + i] = ((uint32_t)j * srs_n + i) | (neg << 31);
   }
 }
 
-// bstart[k] = first sorted entry with key >= k, k = 0..NBUCKET  (bstart[NBUCKET] = #real entries)
-__global__ void msm_bounds_kernel(const uint16_t* keys, uint32_t m, uint32_t* bstart) {
+// bstart[k] = first sorted entry with key >= k, k = 0..NB  (bstart[NB] = #real entries);
+// lkey[k] = 255 - min(len_k, 255) (ascending sort => longest buckets first), lval[k] = k
+template <int WB>
+__global__ void msm_bounds_kernel(const typename Win<WB>::Key* keys, uint32_t m, uint32_t* bstart) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > NBUCKET) return;
+  if (k > Win<WB>::NB) return;
   uint32_t lo = 0, hi = m;
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -268,55 +286,43 @@ __global__ void msm_bounds_kernel(const uint16_t* keys, uint32_t m, uint32_t* bs
   }
   bstart[k] = lo;
 }
-
-// slice_off[k] = sum_{k' < k} ceil(len_k' / SEG), k = 0..NBUCKET.  One block of 1024 threads.
-__global__ __launch_bounds__(1024) void msm_slices_kernel(const uint32_t* bstart, uint32_t* slice_off) {
-  __shared__ uint32_t part[1024];
-  const uint32_t t = threadIdx.x;
-  constexpr uint32_t PER = NBUCKET / 1024;
-  uint32_t cnt[PER];
-  uint32_t sum = 0;
-#pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) {
-    const uint32_t k = t * PER + q;
-    const uint32_t len = bstart[k + 1] - bstart[k];
-    cnt[q] = (len + SEG - 1) / SEG;
-    sum += cnt[q];
-  }
-  part[t] = sum;
-  __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {
-    const uint32_t v = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[t] - sum;   // exclusive prefix of this thread's first bucket
-#pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) {
-    slice_off[t * PER + q] = run;
-    run += cnt[q];
-  }
-  if (t == 1023) slice_off[NBUCKET] = run;
+template <int WB>
+__global__ void msm_lenkey_kernel(const uint32_t* bstart, uint8_t* lkey, uint32_t* lval) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Win<WB>::NB) return;
+  const uint32_t len = bstart[k + 1] - bstart[k];
+  lkey[k] = (uint8_t)(255u - min(len, 255u));
+  lval[k] = k;
+}
+// ns[r] = slices of the r-th bucket in length order; ns[NB] = 0 (so the scan yields the total)
+template <int WB>
+__global__ void msm_ns_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t* ns) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > Win<WB>::NB) return;
+  if (r == Win<WB>::NB) { ns[r] = 0; return; }
+  const uint32_t k = order[r];
+  ns[r] = (bstart[k + 1] - bstart[k] + Win<WB>::SEG - 1) / Win<WB>::SEG;
 }
 
-template <class C>
+template <class C, int WB>
 __global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
-                                                             const uint32_t* bstart, const uint32_t* slice_off,
-                                                             uint32_t* partials) {
+                                                             const uint32_t* bstart, const uint32_t* order,
+                                                             const uint32_t* slice_off, uint32_t* partials) {
   using F = typename C::Fp;
   using Fd = Field<F>;
+  constexpr uint32_t NB = Win<WB>::NB;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= slice_off[NBUCKET]) return;
-  // bucket of slice t: largest k with slice_off[k] <= t
-  uint32_t lo = 0, hi = NBUCKET;
+  if (t >= slice_off[NB]) return;
+  // rank of the bucket of slice t: largest r with slice_off[r] <= t
+  uint32_t lo = 0, hi = NB;
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
     if (slice_off[mid] <= t) lo = mid; else hi = mid;
   }
-  const uint32_t k = lo;
-  const uint32_t s = t - slice_off[k];
-  const uint32_t ns = slice_off[k + 1] - slice_off[k];
+  const uint32_t r = lo;
+  const uint32_t k = order[r];
+  const uint32_t s = t - slice_off[r];
+  const uint32_t ns = slice_off[r + 1] - slice_off[r];
   const uint32_t b0 = bstart[k];
   const uint32_t len = bstart[k + 1] - b0;
   const uint32_t e0 = b0 + (uint32_t)(((uint64_t)s * len) / ns);
@@ -333,60 +339,83 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* rec
   store_xyzz<C>(partials, t, acc);
 }
 
-// FIN_LANES lanes per bucket fold that bucket's slice partials
-template <class C>
-__global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* partials, const uint32_t* slice_off,
-                                                           uint32_t* buckets) {
+// FIN lanes per bucket (in length order) fold that bucket's slice partials
+template <class C, int WB>
+__global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* partials, const uint32_t* order,
+                                                           const uint32_t* slice_off, uint32_t* buckets) {
+  constexpr uint32_t FIN = Win<WB>::FIN, NB = Win<WB>::NB;
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t k = gt / FIN_LANES, g = gt % FIN_LANES;
+  const uint32_t r = gt / FIN, g = gt % FIN;
   XYZZ<C> acc = Ec<C>::infinity();
-  if (k < NBUCKET) {
-    const uint32_t p0 = slice_off[k], p1 = slice_off[k + 1];
-    for (uint32_t p = p0 + g; p < p1; p += FIN_LANES) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
+  if (r < NB) {
+    const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
+    for (uint32_t p = p0 + g; p < p1; p += FIN) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
   }
 #pragma unroll
-  for (int m = 1; m < (int)FIN_LANES; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
-  if (k < NBUCKET && g == 0) store_xyzz<C>(buckets, k, acc);
+  for (int m = 1; m < (int)FIN; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  if (r < NB && g == 0) store_xyzz<C>(buckets, order[r], acc);
 }
 
-// stage 1 of the bit-plane reduction: grid (RED_WAVES, 15); one wave per block.
-// T_b = sum of buckets whose magnitude v = k+1 has bit b set (v in 1..32767).
-template <class C>
-__global__ __launch_bounds__(64) void msm_reduce1_kernel(const uint32_t* buckets, uint32_t* bitpart) {
-  const uint32_t b = blockIdx.y, wv = blockIdx.x, lane = threadIdx.x;
+// Block-wide sum of `count` bucket-matrix entries v = base_v + e*stride_v (entry v is
+// buckets[v-1]; v = 0 is the empty digit).  blockIdx.y = 0: rows (block b = row b),
+// blockIdx.y = 1: columns.  128 threads: serial part, 6 shuffle levels, LDS across 2 waves.
+template <class C, int WB>
+__global__ __launch_bounds__(128) void msm_rowcol_kernel(const uint32_t* buckets, uint32_t* rowsum,
+                                                         uint32_t* colsum) {
+  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI, N = C::Fp::N;
+  __shared__ uint32_t xch[4 * N];
+  const bool cols = blockIdx.y == 1;
+  const uint32_t b = blockIdx.x;
+  const uint32_t nseg = cols ? (1u << LO) : (1u << HI);
+  if (b >= nseg) return;                                   // whole block exits together
+  const uint32_t count = cols ? (1u << HI) : (1u << LO);
+  const uint32_t base_v = cols ? b : (b << LO);
+  const uint32_t stride_v = cols ? (1u << LO) : 1u;
   XYZZ<C> acc = Ec<C>::infinity();
-#pragma unroll 1
-  for (uint32_t q4 = 0; q4 < RED_PER_LANE; ++q4) {
-    const uint32_t q = (wv * 64 + lane) * RED_PER_LANE + q4;       // q-th 15-bit value with bit b set
-    const uint32_t v = ((q >> b) << (b + 1)) | (1u << b) | (q & ((1u << b) - 1));
-    acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
+  for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+    const uint32_t v = base_v + e * stride_v;
+    if (v) acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
-  if (lane == 0) store_xyzz<C>(bitpart, b * RED_WAVES + wv, acc);
+  if (threadIdx.x == 64) store_xyzz<C>(xch, 0, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc = Ec<C>::add(acc, load_xyzz<C>(xch, 0));
+    store_xyzz<C>(cols ? colsum : rowsum, b, acc);
+  }
 }
-// stage 2: one wave per bit folds RED_WAVES partials; bit 15 is the single bucket 32768
-template <class C>
-__global__ __launch_bounds__(64) void msm_reduce2_kernel(const uint32_t* bitpart, const uint32_t* buckets,
-                                                         uint32_t* tb) {
-  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+
+// bit-plane sums of the row-sum and column-sum vectors: block b < HI: T = sum of rowsum[i]
+// with bit b of i set; block HI + b: same over colsum; last block: the top bucket (v = 2^(WB-1)).
+template <class C, int WB>
+__global__ __launch_bounds__(64) void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
+                                                        const uint32_t* buckets, uint32_t* out) {
+  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
+  const uint32_t blk = blockIdx.x, lane = threadIdx.x;
   XYZZ<C> acc = Ec<C>::infinity();
-  if (b < 15) {
-    if (lane < RED_WAVES) acc = load_xyzz<C>(bitpart, b * RED_WAVES + lane);
+  if (blk < (uint32_t)(HI + LO)) {
+    const bool cols = blk >= (uint32_t)HI;
+    const uint32_t b = cols ? blk - HI : blk;
+    const uint32_t members = (cols ? (1u << LO) : (1u << HI)) >> 1;
+    const uint32_t* src = cols ? colsum : rowsum;
+    for (uint32_t q = lane; q < members; q += 64) {
+      const uint32_t i = ((q >> b) << (b + 1)) | (1u << b) | (q & ((1u << b) - 1));   // q-th index with bit b set
+      acc = Ec<C>::add(acc, load_xyzz<C>(src, i));
+    }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
   } else {
-    acc = load_xyzz<C>(buckets, NBUCKET - 1);
+    acc = load_xyzz<C>(buckets, Win<WB>::NB - 1);
   }
-  if (lane == 0) store_xyzz<C>(tb, b, acc);
+  if (lane == 0) store_xyzz<C>(out, blk, acc);
 }
 
 template <class C>
 size_t rec_bytes() { return (size_t)C::REC_WORDS * 4; }
 
-struct SortTemp {
-  size_t bytes = 0;
-};
+int pick_win_bits(size_t n) { return n >= (1u << 18) ? 20 : 16; }
+int nwin_of(int wb) { return (256 + wb - 1) / wb; }
 
 }  // namespace
 
@@ -396,23 +425,31 @@ template <class C>
 static int srs_build_windows(Ctx* c, Srs* s) {
   const size_t n = s->n;
   const uint32_t blocks = (uint32_t)((n + 127) / 128);
-  for (int j = 1; j < NWIN; ++j) {
+  for (int j = 1; j < s->nwin; ++j) {
     hipLaunchKernelGGL(srs_window_kernel<C>, dim3(blocks), dim3(128), 0, c->stream,
-                       s->recs + (size_t)(j - 1) * n * C::REC_WORDS, s->recs + (size_t)j * n * C::REC_WORDS, n);
+                       s->recs + (size_t)(j - 1) * n * C::REC_WORDS, s->recs + (size_t)j * n * C::REC_WORDS, n,
+                       s->win_bits);
     KZG_HIP(c, hipGetLastError());
   }
   KZG_HIP(c, hipStreamSynchronize(c->stream));
   return KZG_OK;
 }
 
-template <class C>
-static int srs_load_t(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
-  using F = typename C::Fp;
-  if (n == 0 || n * (size_t)NWIN >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_load_g1: bad size");
+static Srs* srs_alloc(Ctx* c, size_t n) {
   Srs* s = new Srs();
   s->n = n;
   s->curve = c->curve;
-  const size_t table_bytes = (size_t)NWIN * n * rec_bytes<C>();
+  s->win_bits = pick_win_bits(n);
+  s->nwin = nwin_of(s->win_bits);
+  return s;
+}
+
+template <class C>
+static int srs_load_t(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
+  using F = typename C::Fp;
+  if (n == 0 || n * (size_t)16 >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_load_g1: bad size");
+  Srs* s = srs_alloc(c, n);
+  const size_t table_bytes = (size_t)s->nwin * n * rec_bytes<C>();
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->recs), table_bytes);
   if (e != hipSuccess) { delete s; return set_err(c, KZG_ERR_ALLOC, "hipMalloc(SRS table)", e); }
   uint32_t* d_xy = nullptr; uint8_t* d_inf = nullptr; uint32_t* d_bad = nullptr;
@@ -444,11 +481,9 @@ static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t start, size_
                           Srs** out) {
   using F = typename C::Fp;
   using Fr = typename C::Fr;
-  if (n == 0 || n * (size_t)NWIN >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_generate: bad size");
-  Srs* s = new Srs();
-  s->n = n;
-  s->curve = c->curve;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->recs), (size_t)NWIN * n * rec_bytes<C>());
+  if (n == 0 || n * (size_t)16 >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_generate: bad size");
+  Srs* s = srs_alloc(c, n);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->recs), (size_t)s->nwin * n * rec_bytes<C>());
   if (e != hipSuccess) { delete s; return set_err(c, KZG_ERR_ALLOC, "hipMalloc(SRS table)", e); }
   uint32_t *d_g = nullptr, *d_tab = nullptr, *d_tau = nullptr, *d_xy = nullptr, *d_bad = nullptr;
   auto cleanup = [&]() { hipFree(d_g); hipFree(d_tab); hipFree(d_tau); hipFree(d_xy); hipFree(d_bad); };
@@ -520,25 +555,25 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
                        : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
 }
 
-// Commit pipeline.  Stage A (digits, sort, bounds, accumulate) runs on the context's stream;
-// stage B (finalize, bit-plane reduce, copy of the 16 T_b to pinned host memory) runs on an
-// auxiliary stream behind an event, so the latency-bound stage B of polynomial p overlaps the
-// ALU-bound stage A of polynomial p+1.  Stage-B buffers are double-buffered in two slots; the host
-// finishes a polynomial (Horner + one inversion) when its slot is recycled or at the end of the call.
+// Commit pipeline.  Stage A runs on the context's stream; stage B runs on an auxiliary stream
+// behind an event, so the latency-bound stage B of polynomial p overlaps the ALU-bound stage A of
+// polynomial p+1.  Stage-B buffers are double-buffered in two slots; the host finishes a
+// polynomial (Horner + one inversion) when its slot is recycled or at the end of the call.
 constexpr int NSLOT = 2;
 
 struct MsmSlot {
-  DevBuf slice_off, partials, buckets, bitpart, tb;
-  void* h_tb = nullptr;        // pinned host copy of the 16 T_b
-  hipEvent_t ev_a = nullptr;   // stage A done (partials, slice_off ready)
+  DevBuf order, slice_off, partials, buckets, rowsum, colsum, tb;
+  void* h_tb = nullptr;        // pinned host copy of the partial points
+  hipEvent_t ev_a = nullptr;   // stage A done
   hipEvent_t ev_b = nullptr;   // stage B done (h_tb ready)
   bool pending = false;
+  int win_bits = 0;
   uint64_t* out_xy = nullptr;
   uint8_t* out_inf = nullptr;
 };
 
 struct MsmWork {
-  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart;    // stage A only
+  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart, lkey_a, lkey_b, lval_a, ns;    // stage A only
   MsmSlot slot[NSLOT];
   hipStream_t stream_b = nullptr;
   int next = 0;
@@ -551,9 +586,12 @@ static MsmWork* get_work(Ctx* c) {
 void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
-  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart}) hipFree(b->p);
+  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart, &w->lkey_a,
+                    &w->lkey_b, &w->lval_a, &w->ns})
+    hipFree(b->p);
   for (auto& sl : w->slot) {
-    for (DevBuf* b : {&sl.slice_off, &sl.partials, &sl.buckets, &sl.bitpart, &sl.tb}) hipFree(b->p);
+    for (DevBuf* b : {&sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.tb})
+      hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
     if (sl.ev_a) hipEventDestroy(sl.ev_a);
     if (sl.ev_b) hipEventDestroy(sl.ev_b);
@@ -563,100 +601,137 @@ void msm_free_work(Ctx* c) {
   c->msm_work = nullptr;
 }
 
-template <class C>
+template <class C, int WB>
 static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, MsmSlot& sl) {
+  using W = Win<WB>;
+  using Key = typename W::Key;
   constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
-  const uint32_t m = n * NWIN;
-  const uint32_t max_slices = m / SEG + NBUCKET + 1;
+  constexpr uint32_t NB = W::NB;
+  const uint32_t m = n * W::NWIN;
+  const uint32_t max_slices = m / W::SEG + NB + 1;
   int rc;
-  if ((rc = ensure_buf(c, w->keys_a, (size_t)m * 2))) return rc;
-  if ((rc = ensure_buf(c, w->keys_b, (size_t)m * 2))) return rc;
+  if ((rc = ensure_buf(c, w->keys_a, (size_t)m * sizeof(Key)))) return rc;
+  if ((rc = ensure_buf(c, w->keys_b, (size_t)m * sizeof(Key)))) return rc;
   if ((rc = ensure_buf(c, w->vals_a, (size_t)m * 4))) return rc;
   if ((rc = ensure_buf(c, w->vals_b, (size_t)m * 4))) return rc;
-  if ((rc = ensure_buf(c, w->bstart, (NBUCKET + 2) * 4))) return rc;
-  if ((rc = ensure_buf(c, sl.slice_off, (NBUCKET + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, w->bstart, (size_t)(NB + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, w->lkey_a, NB))) return rc;
+  if ((rc = ensure_buf(c, w->lkey_b, NB))) return rc;
+  if ((rc = ensure_buf(c, w->lval_a, (size_t)NB * 4))) return rc;
+  if ((rc = ensure_buf(c, w->ns, (size_t)(NB + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.order, (size_t)NB * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.slice_off, (size_t)(NB + 2) * 4))) return rc;
   if ((rc = ensure_buf(c, sl.partials, (size_t)max_slices * PT))) return rc;
-  if ((rc = ensure_buf(c, sl.buckets, (size_t)NBUCKET * PT))) return rc;
-  if ((rc = ensure_buf(c, sl.bitpart, (size_t)15 * RED_WAVES * PT))) return rc;
-  if ((rc = ensure_buf(c, sl.tb, (size_t)16 * PT))) return rc;
-  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, 16 * 4 * 16 * 4));
+  if ((rc = ensure_buf(c, sl.buckets, (size_t)NB * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.rowsum, ((size_t)1 << W::HI) * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.colsum, ((size_t)1 << W::LO) * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.tb, (size_t)MAX_NPART * PT))) return rc;
+  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
   if (!sl.ev_a) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_a, hipEventDisableTiming));
   if (!sl.ev_b) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_b, hipEventDisableTiming));
   if (!w->stream_b) KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_b, hipStreamNonBlocking));
+  sl.win_bits = WB;
 
-  auto* keys_a = static_cast<uint16_t*>(w->keys_a.p);
-  auto* keys_b = static_cast<uint16_t*>(w->keys_b.p);
+  auto* keys_a = static_cast<Key*>(w->keys_a.p);
+  auto* keys_b = static_cast<Key*>(w->keys_b.p);
   auto* vals_a = static_cast<uint32_t*>(w->vals_a.p);
   auto* vals_b = static_cast<uint32_t*>(w->vals_b.p);
-  size_t tmp_bytes = 0;
-  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
-                                       c->stream));
-  if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
+  auto* lkey_a = static_cast<uint8_t*>(w->lkey_a.p);
+  auto* lkey_b = static_cast<uint8_t*>(w->lkey_b.p);
+  auto* lval_a = static_cast<uint32_t*>(w->lval_a.p);
+  auto* ns = static_cast<uint32_t*>(w->ns.p);
+  auto* bstart = static_cast<uint32_t*>(w->bstart.p);
+  auto* order = static_cast<uint32_t*>(sl.order.p);
+  auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
+  hipStream_t sa = c->stream, sb = w->stream_b;
+
+  constexpr unsigned SORT_BITS = WB <= 16 ? 16 : WB;
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sa));
+  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sa));
+  KZG_HIP(c, rocprim::exclusive_scan(nullptr, t3, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sa));
+  const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, (size_t)16));
+  if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes))) return rc;
 
   // ---- stage A on the context's stream
-  hipStream_t sa = c->stream, sb = w->stream_b;
   {
     ProfScope ps(c, "msm_digits");
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((n + 255) / 256), dim3(256), 0, sa, d_scalars, s->recs,
+    hipLaunchKernelGGL(msm_digits_kernel<WB>, dim3((n + 255) / 256), dim3(256), 0, sa, d_scalars, s->recs,
                        (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
   }
   KZG_HIP(c, hipGetLastError());
   {
     ProfScope ps(c, "msm_sort");
-    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, 16,
+    size_t tb = tmp_bytes;
+    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tb, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS,
                                          sa));
   }
-  auto* bstart = static_cast<uint32_t*>(w->bstart.p);
-  auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
   {
     ProfScope ps(c, "msm_bounds");
-    hipLaunchKernelGGL(msm_bounds_kernel, dim3((NBUCKET + 1 + 255) / 256), dim3(256), 0, sa, keys_b, m, bstart);
-    hipLaunchKernelGGL(msm_slices_kernel, dim3(1), dim3(1024), 0, sa, bstart, slice_off);
+    hipLaunchKernelGGL(msm_bounds_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sa, keys_b, m, bstart);
+    hipLaunchKernelGGL(msm_lenkey_kernel<WB>, dim3((NB + 255) / 256), dim3(256), 0, sa, bstart, lkey_a, lval_a);
+    size_t tb = tmp_bytes;
+    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tb, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sa));
+    hipLaunchKernelGGL(msm_ns_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sa, bstart, order, ns);
+    tb = tmp_bytes;
+    KZG_HIP(c, rocprim::exclusive_scan(w->sort_tmp.p, tb, ns, slice_off, 0u, (size_t)NB + 1,
+                                       rocprim::plus<uint32_t>(), sa));
   }
   {
     ProfScope ps(c, "msm_accumulate");
-    hipLaunchKernelGGL(msm_accumulate_kernel<C>, dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
-                       vals_b, bstart, slice_off, static_cast<uint32_t*>(sl.partials.p));
+    hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
+                       vals_b, bstart, order, slice_off, static_cast<uint32_t*>(sl.partials.p));
   }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipEventRecord(sl.ev_a, sa));
 
-  // ---- stage B on the auxiliary stream
+  // ---- stage B on the auxiliary stream.  bstart is not read here (stage A of the next
+  // polynomial overwrites it); order / slice_off / partials / buckets belong to the slot.
   KZG_HIP(c, hipStreamWaitEvent(sb, sl.ev_a, 0));
   {
     ProfScope ps(c, "msm_finalize", sb);
-    hipLaunchKernelGGL(msm_finalize_kernel<C>, dim3(NBUCKET * FIN_LANES / 128), dim3(128), 0, sb,
-                       static_cast<uint32_t*>(sl.partials.p), slice_off, static_cast<uint32_t*>(sl.buckets.p));
+    hipLaunchKernelGGL((msm_finalize_kernel<C, WB>), dim3((uint32_t)(((uint64_t)NB * W::FIN + 127) / 128)), dim3(128),
+                       0, sb, static_cast<uint32_t*>(sl.partials.p), order, slice_off,
+                       static_cast<uint32_t*>(sl.buckets.p));
   }
   {
     ProfScope ps(c, "msm_reduce", sb);
-    hipLaunchKernelGGL(msm_reduce1_kernel<C>, dim3(RED_WAVES, 15), dim3(64), 0, sb,
-                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.bitpart.p));
-    hipLaunchKernelGGL(msm_reduce2_kernel<C>, dim3(16), dim3(64), 0, sb, static_cast<uint32_t*>(sl.bitpart.p),
+    hipLaunchKernelGGL((msm_rowcol_kernel<C, WB>), dim3(1u << W::LO, 2), dim3(128), 0, sb,
+                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.rowsum.p),
+                       static_cast<uint32_t*>(sl.colsum.p));
+    hipLaunchKernelGGL((msm_planes_kernel<C, WB>), dim3(W::NPART), dim3(64), 0, sb,
+                       static_cast<uint32_t*>(sl.rowsum.p), static_cast<uint32_t*>(sl.colsum.p),
                        static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.tb.p));
   }
   KZG_HIP(c, hipGetLastError());
-  KZG_HIP(c, hipMemcpyAsync(sl.h_tb, sl.tb.p, 16 * PT, hipMemcpyDeviceToHost, sb));
+  KZG_HIP(c, hipMemcpyAsync(sl.h_tb, sl.tb.p, W::NPART * PT, hipMemcpyDeviceToHost, sb));
   KZG_HIP(c, hipEventRecord(sl.ev_b, sb));
   return KZG_OK;
 }
 
-// host: sum_b 2^b T_b, to affine, canonical words
-template <class C>
+// host: 2^LO * sum_b 2^b TR_b + sum_b 2^b TC_b + 2^(WB-1) * top; to affine, canonical words
+template <class C, int WB>
 static void msm_finish_host(const void* h_tb, uint64_t* out_xy, uint8_t* out_inf) {
   using F = typename C::Fp;
   using Fd = Field<F>;
+  using W = Win<WB>;
   constexpr int N = F::N;
   const uint32_t* p = static_cast<const uint32_t*>(h_tb);
-  XYZZ<C> acc = Ec<C>::infinity();
-  for (int b = 15; b >= 0; --b) {
-    acc = Ec<C>::dbl(acc);
+  auto pt = [&](int idx) {
     XYZZ<C> t;
-    memcpy(t.x.l, p + (size_t)b * 4 * N, N * 4);
-    memcpy(t.y.l, p + (size_t)b * 4 * N + N, N * 4);
-    memcpy(t.zz.l, p + (size_t)b * 4 * N + 2 * N, N * 4);
-    memcpy(t.zzz.l, p + (size_t)b * 4 * N + 3 * N, N * 4);
-    acc = Ec<C>::add(acc, t);
+    memcpy(t.x.l, p + (size_t)idx * 4 * N, N * 4);
+    memcpy(t.y.l, p + (size_t)idx * 4 * N + N, N * 4);
+    memcpy(t.zz.l, p + (size_t)idx * 4 * N + 2 * N, N * 4);
+    memcpy(t.zzz.l, p + (size_t)idx * 4 * N + 3 * N, N * 4);
+    return t;
+  };
+  // acc = top * 2^(HI-1) ... folded into one Horner chain over descending powers of two:
+  //   total = sum_{b<HI} 2^(LO+b) TR_b + sum_{b<LO} 2^b TC_b + 2^(WB-1) top,   WB-1 = HI+LO
+  XYZZ<C> acc = pt(W::HI + W::LO);                       // coefficient of 2^(HI+LO)
+  for (int e = W::HI + W::LO - 1; e >= 0; --e) {
+    acc = Ec<C>::dbl(acc);
+    if (e >= W::LO) acc = Ec<C>::add(acc, pt(e - W::LO));          // TR_{e-LO}
+    if (e < W::LO) acc = Ec<C>::add(acc, pt(W::HI + e));           // TC_e
   }
   const Affine<C> a = Ec<C>::to_affine(acc);
   uint32_t* o = reinterpret_cast<uint32_t*>(out_xy);
@@ -674,7 +749,8 @@ template <class C>
 static int msm_retire(Ctx* c, MsmSlot& sl) {
   if (!sl.pending) return KZG_OK;
   KZG_HIP(c, hipEventSynchronize(sl.ev_b));
-  msm_finish_host<C>(sl.h_tb, sl.out_xy, sl.out_inf);
+  if (sl.win_bits == 20) msm_finish_host<C, 20>(sl.h_tb, sl.out_xy, sl.out_inf);
+  else msm_finish_host<C, 16>(sl.h_tb, sl.out_xy, sl.out_inf);
   sl.pending = false;
   return KZG_OK;
 }
@@ -712,7 +788,10 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     MsmSlot& sl = w->slot[w->next];
     w->next = (w->next + 1) % NSLOT;
     if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
-    if ((rc = msm_enqueue<C>(c, s, d_scalars + p * stride * 8, (uint32_t)lens[p], w, sl))) break;
+    const uint32_t* sc = d_scalars + p * stride * 8;
+    rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, sl)
+                           : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, sl);
+    if (rc) break;
     sl.pending = true;
     sl.out_xy = o;
     sl.out_inf = out_inf + p;

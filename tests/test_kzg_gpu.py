@@ -164,6 +164,27 @@ def test_commit_medium_trapdoor(kzgs, curve):
     assert aff(kzg.commit(ck, [small])[0]) == O.normalize(O.commit_trapdoor(small, tau, cv), cv)
 
 
+def test_commit_2_18_bn254_trapdoor(native, kzgs):
+    """2^18 + 5 coefficients on BN254: the 20-bit-window path (keys of >= 2^18 points) on the
+    second curve, with a length that is not a power of two; includes skewed scalars."""
+    cv = O.BN254
+    kzg = kzgs["bn254"]
+    n = (1 << 18) + 5
+    tau = 0x51ab3c7d9e % cv.r
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    rs = np.random.RandomState(19)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(4)
+    raw[1000:3000] = 0
+    raw[3000:5000, 1:] = 0                         # small scalars: only the lowest windows are populated
+    raw[5000:9000] = raw[5000]                     # many equal scalars: a few heavy buckets
+    coeffs = native.limbs_to_ints(raw)
+    ctx = native.get_context("bn254")
+    xy, inf = ctx.commit(ck.srs, raw.reshape(1, n, 4), [n], n)
+    got = native.limbs_to_ints(xy.reshape(2, 4))
+    assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+
+
 def test_commit_full_size_2_20_trapdoor(native, kzgs):
     """BASELINE config 3: degree-2^20 commit on BLS12-381 against a 2^20-point SRS.
     The oracle's naive commit is hours at this size; parity is the trapdoor

@@ -281,6 +281,36 @@ struct Field {
     for (int j = 0; j < N; ++j) r.l[j] = neg ? u.l[j] : t.l[j];
     return r;
   }
+  // ---- lazy forms (NTT butterflies): no value reduction, limbs may exceed 2^L --------------
+  // a + b limb-wise.  Caller keeps limbs below 2^32.
+  static KZG_HD E add_lazy(const E& a, const E& b) {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = a.l[j] + b.l[j];
+    return r;
+  }
+  // a - b + 4p limb-wise, for a normalised b < 2p (e.g. a mul() output): every limb of the
+  // redistributed constant P4R dominates the matching limb of b, so no limb goes negative.
+  static KZG_HD E sub_lazy4(const E& a, const E& b) {
+    E r;
+#pragma unroll
+    for (int j = 0; j < N; ++j) r.l[j] = a.l[j] + (F::P4R[j] - b.l[j]);
+    return r;
+  }
+  // carry propagation: limbs back below 2^L (the top limb absorbs the excess), value unchanged
+  static KZG_HD E carry(const E& a) {
+    E r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint32_t t = a.l[j] + c;
+      r.l[j] = t & MASK;
+      c = t >> L;
+    }
+    r.l[N - 1] = a.l[N - 1] + c;
+    return r;
+  }
+
   static KZG_HD E dbl(const E& a) { return add(a, a); }
   static KZG_HD E neg(const E& a) { return sub(zero(), a); }
 

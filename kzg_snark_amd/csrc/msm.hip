@@ -555,17 +555,25 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
                        : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
 }
 
-// Commit pipeline.  Stage A runs on the context's stream; stage B runs on an auxiliary stream
-// behind an event, so the latency-bound stage B of polynomial p overlaps the ALU-bound stage A of
-// polynomial p+1.  Stage-B buffers are double-buffered in two slots; the host finishes a
-// polynomial (Horner + one inversion) when its slot is recycled or at the end of the call.
-constexpr int NSLOT = 2;
+// Commit pipeline: three stages on three internal streams, three polynomials in flight.
+//   P  prep        digits, sort, bounds, bucket order, slices      (memory-bound)
+//   A  accumulate  the mixed-addition kernel                        (ALU-bound)
+//   B  reduce      finalize, row/column sums, bit planes, copy-out  (latency-bound)
+// prep(p+1), accumulate(p) and reduce(p-1) run concurrently.  The context's stream only
+// carries ordering: P waits for everything enqueued on it before the call (the scalars), and it
+// waits for P to have consumed the scalars, so later work on the context's stream (the next NTT)
+// can neither race with prep nor queue behind accumulate.  Every buffer belongs to a slot; the
+// host finishes a polynomial (Horner + one inversion) when its slot is recycled or on flush.
+constexpr int NSLOT = 3;
 
 struct MsmSlot {
+  DevBuf keys_a, keys_b, vals_a, vals_b, bstart, lkey_a, lkey_b, lval_a, ns;       // prep
   DevBuf order, slice_off, partials, buckets, rowsum, colsum, tb;
   void* h_tb = nullptr;        // pinned host copy of the partial points
-  hipEvent_t ev_a = nullptr;   // stage A done
-  hipEvent_t ev_b = nullptr;   // stage B done (h_tb ready)
+  hipEvent_t ev_in = nullptr;  // inputs ready on the context's stream
+  hipEvent_t ev_p = nullptr;   // prep done
+  hipEvent_t ev_a = nullptr;   // accumulate done
+  hipEvent_t ev_b = nullptr;   // reduce done (h_tb ready)
   bool pending = false;
   int win_bits = 0;
   uint64_t* out_xy = nullptr;
@@ -573,9 +581,9 @@ struct MsmSlot {
 };
 
 struct MsmWork {
-  DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp, bstart, lkey_a, lkey_b, lval_a, ns;    // stage A only
+  DevBuf sort_tmp[NSLOT];
   MsmSlot slot[NSLOT];
-  hipStream_t stream_b = nullptr;
+  hipStream_t stream_p = nullptr, stream_a = nullptr, stream_b = nullptr;
   int next = 0;
 };
 
@@ -586,39 +594,40 @@ static MsmWork* get_work(Ctx* c) {
 void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
-  for (DevBuf* b : {&w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->sort_tmp, &w->bstart, &w->lkey_a,
-                    &w->lkey_b, &w->lval_a, &w->ns})
-    hipFree(b->p);
+  for (auto& b : w->sort_tmp) hipFree(b.p);
   for (auto& sl : w->slot) {
-    for (DevBuf* b : {&sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.tb})
+    for (DevBuf* b : {&sl.keys_a, &sl.keys_b, &sl.vals_a, &sl.vals_b, &sl.bstart, &sl.lkey_a, &sl.lkey_b, &sl.lval_a,
+                      &sl.ns, &sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.tb})
       hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
-    if (sl.ev_a) hipEventDestroy(sl.ev_a);
-    if (sl.ev_b) hipEventDestroy(sl.ev_b);
+    for (hipEvent_t e : {sl.ev_in, sl.ev_p, sl.ev_a, sl.ev_b})
+      if (e) hipEventDestroy(e);
   }
-  if (w->stream_b) hipStreamDestroy(w->stream_b);
+  for (hipStream_t st : {w->stream_p, w->stream_a, w->stream_b})
+    if (st) hipStreamDestroy(st);
   delete w;
   c->msm_work = nullptr;
 }
 
 template <class C, int WB>
-static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, MsmSlot& sl) {
+static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, int slot_idx) {
   using W = Win<WB>;
   using Key = typename W::Key;
   constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
   constexpr uint32_t NB = W::NB;
+  MsmSlot& sl = w->slot[slot_idx];
   const uint32_t m = n * W::NWIN;
   const uint32_t max_slices = m / W::SEG + NB + 1;
   int rc;
-  if ((rc = ensure_buf(c, w->keys_a, (size_t)m * sizeof(Key)))) return rc;
-  if ((rc = ensure_buf(c, w->keys_b, (size_t)m * sizeof(Key)))) return rc;
-  if ((rc = ensure_buf(c, w->vals_a, (size_t)m * 4))) return rc;
-  if ((rc = ensure_buf(c, w->vals_b, (size_t)m * 4))) return rc;
-  if ((rc = ensure_buf(c, w->bstart, (size_t)(NB + 2) * 4))) return rc;
-  if ((rc = ensure_buf(c, w->lkey_a, NB))) return rc;
-  if ((rc = ensure_buf(c, w->lkey_b, NB))) return rc;
-  if ((rc = ensure_buf(c, w->lval_a, (size_t)NB * 4))) return rc;
-  if ((rc = ensure_buf(c, w->ns, (size_t)(NB + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.keys_a, (size_t)m * sizeof(Key)))) return rc;
+  if ((rc = ensure_buf(c, sl.keys_b, (size_t)m * sizeof(Key)))) return rc;
+  if ((rc = ensure_buf(c, sl.vals_a, (size_t)m * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.vals_b, (size_t)m * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.bstart, (size_t)(NB + 2) * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.lkey_a, NB))) return rc;
+  if ((rc = ensure_buf(c, sl.lkey_b, NB))) return rc;
+  if ((rc = ensure_buf(c, sl.lval_a, (size_t)NB * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.ns, (size_t)(NB + 2) * 4))) return rc;
   if ((rc = ensure_buf(c, sl.order, (size_t)NB * 4))) return rc;
   if ((rc = ensure_buf(c, sl.slice_off, (size_t)(NB + 2) * 4))) return rc;
   if ((rc = ensure_buf(c, sl.partials, (size_t)max_slices * PT))) return rc;
@@ -627,66 +636,73 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.colsum, ((size_t)1 << W::LO) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.tb, (size_t)MAX_NPART * PT))) return rc;
   if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
-  if (!sl.ev_a) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_a, hipEventDisableTiming));
-  if (!sl.ev_b) KZG_HIP(c, hipEventCreateWithFlags(&sl.ev_b, hipEventDisableTiming));
-  if (!w->stream_b) KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_b, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
+    if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b})
+    if (!*st) KZG_HIP(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
   sl.win_bits = WB;
 
-  auto* keys_a = static_cast<Key*>(w->keys_a.p);
-  auto* keys_b = static_cast<Key*>(w->keys_b.p);
-  auto* vals_a = static_cast<uint32_t*>(w->vals_a.p);
-  auto* vals_b = static_cast<uint32_t*>(w->vals_b.p);
-  auto* lkey_a = static_cast<uint8_t*>(w->lkey_a.p);
-  auto* lkey_b = static_cast<uint8_t*>(w->lkey_b.p);
-  auto* lval_a = static_cast<uint32_t*>(w->lval_a.p);
-  auto* ns = static_cast<uint32_t*>(w->ns.p);
-  auto* bstart = static_cast<uint32_t*>(w->bstart.p);
+  auto* keys_a = static_cast<Key*>(sl.keys_a.p);
+  auto* keys_b = static_cast<Key*>(sl.keys_b.p);
+  auto* vals_a = static_cast<uint32_t*>(sl.vals_a.p);
+  auto* vals_b = static_cast<uint32_t*>(sl.vals_b.p);
+  auto* lkey_a = static_cast<uint8_t*>(sl.lkey_a.p);
+  auto* lkey_b = static_cast<uint8_t*>(sl.lkey_b.p);
+  auto* lval_a = static_cast<uint32_t*>(sl.lval_a.p);
+  auto* ns = static_cast<uint32_t*>(sl.ns.p);
+  auto* bstart = static_cast<uint32_t*>(sl.bstart.p);
   auto* order = static_cast<uint32_t*>(sl.order.p);
   auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
-  hipStream_t sa = c->stream, sb = w->stream_b;
+  hipStream_t sp = w->stream_p, sa = w->stream_a, sb = w->stream_b;
 
   constexpr unsigned SORT_BITS = WB <= 16 ? 16 : WB;
   size_t t1 = 0, t2 = 0, t3 = 0;
-  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sa));
-  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sa));
-  KZG_HIP(c, rocprim::exclusive_scan(nullptr, t3, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sa));
+  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sp));
+  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sp));
+  KZG_HIP(c, rocprim::exclusive_scan(nullptr, t3, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sp));
   const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, (size_t)16));
-  if ((rc = ensure_buf(c, w->sort_tmp, tmp_bytes))) return rc;
+  DevBuf& tmp = w->sort_tmp[slot_idx];
+  if ((rc = ensure_buf(c, tmp, tmp_bytes))) return rc;
 
-  // ---- stage A on the context's stream
+  // ---- stage P: prep
+  KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));
+  KZG_HIP(c, hipStreamWaitEvent(sp, sl.ev_in, 0));
   {
-    ProfScope ps(c, "msm_digits");
-    hipLaunchKernelGGL(msm_digits_kernel<WB>, dim3((n + 255) / 256), dim3(256), 0, sa, d_scalars, s->recs,
+    ProfScope ps(c, "msm_digits", sp);
+    hipLaunchKernelGGL(msm_digits_kernel<WB>, dim3((n + 255) / 256), dim3(256), 0, sp, d_scalars, s->recs,
                        (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
   }
   KZG_HIP(c, hipGetLastError());
   {
-    ProfScope ps(c, "msm_sort");
+    ProfScope ps(c, "msm_sort", sp);
     size_t tb = tmp_bytes;
-    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tb, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS,
-                                         sa));
+    KZG_HIP(c, rocprim::radix_sort_pairs(tmp.p, tb, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sp));
   }
   {
-    ProfScope ps(c, "msm_bounds");
-    hipLaunchKernelGGL(msm_bounds_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sa, keys_b, m, bstart);
-    hipLaunchKernelGGL(msm_lenkey_kernel<WB>, dim3((NB + 255) / 256), dim3(256), 0, sa, bstart, lkey_a, lval_a);
+    ProfScope ps(c, "msm_bounds", sp);
+    hipLaunchKernelGGL(msm_bounds_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sp, keys_b, m, bstart);
+    hipLaunchKernelGGL(msm_lenkey_kernel<WB>, dim3((NB + 255) / 256), dim3(256), 0, sp, bstart, lkey_a, lval_a);
     size_t tb = tmp_bytes;
-    KZG_HIP(c, rocprim::radix_sort_pairs(w->sort_tmp.p, tb, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sa));
-    hipLaunchKernelGGL(msm_ns_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sa, bstart, order, ns);
+    KZG_HIP(c, rocprim::radix_sort_pairs(tmp.p, tb, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sp));
+    hipLaunchKernelGGL(msm_ns_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sp, bstart, order, ns);
     tb = tmp_bytes;
-    KZG_HIP(c, rocprim::exclusive_scan(w->sort_tmp.p, tb, ns, slice_off, 0u, (size_t)NB + 1,
-                                       rocprim::plus<uint32_t>(), sa));
+    KZG_HIP(c, rocprim::exclusive_scan(tmp.p, tb, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sp));
   }
+  KZG_HIP(c, hipGetLastError());
+  KZG_HIP(c, hipEventRecord(sl.ev_p, sp));
+  KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
+
+  // ---- stage A: accumulate
+  KZG_HIP(c, hipStreamWaitEvent(sa, sl.ev_p, 0));
   {
-    ProfScope ps(c, "msm_accumulate");
+    ProfScope ps(c, "msm_accumulate", sa);
     hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
                        vals_b, bstart, order, slice_off, static_cast<uint32_t*>(sl.partials.p));
   }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipEventRecord(sl.ev_a, sa));
 
-  // ---- stage B on the auxiliary stream.  bstart is not read here (stage A of the next
-  // polynomial overwrites it); order / slice_off / partials / buckets belong to the slot.
+  // ---- stage B: reduce
   KZG_HIP(c, hipStreamWaitEvent(sb, sl.ev_a, 0));
   {
     ProfScope ps(c, "msm_finalize", sb);
@@ -785,12 +801,13 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
       out_inf[p] = 1;
       continue;
     }
-    MsmSlot& sl = w->slot[w->next];
+    const int si = w->next;
+    MsmSlot& sl = w->slot[si];
     w->next = (w->next + 1) % NSLOT;
     if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
     const uint32_t* sc = d_scalars + p * stride * 8;
-    rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, sl)
-                           : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, sl);
+    rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, si)
+                           : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, si);
     if (rc) break;
     sl.pending = true;
     sl.out_xy = o;

@@ -19,10 +19,20 @@
 //
 // Each workgroup owns one LDS tile of up to 4096 elements (C lines of 2^k
 // elements; 36 B per element: 9 limbs of 29 bits, stride 9 words => conflict-free
-// ds_read_b32/ds_write_b32 across consecutive lanes).  All k stages of the tile
-// run out of LDS with one barrier per stage; HBM is touched once for the load
-// and once for the store of each pass.  Data stays in standard (non-Montgomery)
-// form: twiddles are kept in Montgomery form, so mont_mul(x, tw*R) = x*tw.
+// ds_read_b32/ds_write_b32 across consecutive lanes).  The k levels run out of LDS
+// as fused radix-4 steps (two levels per LDS round trip and barrier; one thread =
+// one 4-point butterfly; a leading radix-2 step when k is odd); HBM is touched once
+// for the load and once for the store of each pass.  Data stays in standard
+// (non-Montgomery) form: twiddles are kept in Montgomery form, so
+// mont_mul(x, tw*R) = x*tw.
+//
+// Arithmetic inside a pass is lazy: a level maps (x, y) to (x + t, x - t + 4p) with
+// t = y*tw < 2p, limbs are only carry-normalised, values grow by at most 4p per
+// level (<= 49p after 12 levels; the 9x29-bit representation holds 70p for
+// BLS12-381 Fr and mul() accepts any operand below R = 2^261).  The multiplication
+// that ends every pass -- the twist w^(t*v) after pass 1, the scale (1 or n^-1) after
+// the last pass -- brings the value back below 2p, one conditional subtraction makes
+// it canonical.
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
@@ -38,9 +48,9 @@ struct NttPassArgs {
   const uint32_t* src;
   uint32_t* dst;
   const uint32_t* stage;   // stage twiddles (Montgomery), root order 2^kmax
-  const uint32_t* twA;     // twist tables or nullptr
-  const uint32_t* twB;
-  const uint32_t* scale;   // optional final scale (Montgomery) or nullptr
+  const uint32_t* twist;   // pass 1: table of w^(pos*col), [line length][row pitch] entries, or nullptr
+  const uint32_t* scale;   // last pass: final multiplier (Montgomery 1 or n^-1), or nullptr
+  uint64_t twist_pitch;    // entries per twist-table row (= N2)
   uint32_t k;              // log2 line length
   uint32_t logC;           // log2 lines per tile
   uint32_t kmax;
@@ -103,40 +113,67 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   }
   __syncthreads();
 
-  // ---- k butterfly stages in LDS
-  for (uint32_t s = 1; s <= k; ++s) {
-    const uint32_t half = 1u << (s - 1);
+  // ---- levels 1..k in LDS.  Level s merges halves of length h = 2^(s-1) with the twiddle
+  // (w^(n/2^s))^i = stage[i << (kmax - s)].
+  uint32_t s = 1;
+  if (k & 1u) {   // odd k: one radix-2 level first (level 1: every twiddle is w^0 = 1)
     for (uint32_t bf = tid; bf < TILE / 2; bf += T) {
       const uint32_t line = bf >> (k - 1);
-      const uint32_t rem = bf & (LEN / 2 - 1);
-      const uint32_t i = rem & (half - 1);
-      const uint32_t blk = rem >> (s - 1);
-      const uint32_t p0 = lds_addr(line, k, (blk << s) + i);
-      const uint32_t p1 = lds_addr(line, k, (blk << s) + i + half);
-      const Fe<F> x = lds_get<F>(lds, p0);
-      Fe<F> y = lds_get<F>(lds, p1);
-      if (s > 1) {  // stage 1 has the single twiddle w^0 = 1 (wave-uniform test)
-        const Fe<F> tw = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s)) * F::N);
-        y = Fd::mul(y, tw);
+      const uint32_t blk = bf & (LEN / 2 - 1);
+      const uint32_t p0 = lds_addr(line, k, blk << 1), p1 = lds_addr(line, k, (blk << 1) + 1);
+      const Fe<F> x = lds_get<F>(lds, p0), y = lds_get<F>(lds, p1);
+      lds_put<F>(lds, p0, Fd::carry(Fd::add_lazy(x, y)));
+      lds_put<F>(lds, p1, Fd::carry(Fd::sub_lazy4(x, y)));
+    }
+    __syncthreads();
+    s = 2;
+  }
+  for (; s < k + 1; s += 2) {   // fused levels (s, s+1): one 4-point butterfly per thread step
+    const uint32_t h = 1u << (s - 1);
+    const bool first = (s == 1);   // level 1 twiddles and the i = 0 twiddle of level 2 are 1
+    for (uint32_t bf = tid; bf < TILE / 4; bf += T) {
+      const uint32_t line = bf >> (k - 2);
+      const uint32_t rem = bf & (LEN / 4 - 1);
+      const uint32_t i = rem & (h - 1);
+      const uint32_t g = rem >> (s - 1);
+      const uint32_t q0 = (g << (s + 1)) + i;
+      const uint32_t a0_ = lds_addr(line, k, q0), a1_ = lds_addr(line, k, q0 + h);
+      const uint32_t a2_ = lds_addr(line, k, q0 + 2 * h), a3_ = lds_addr(line, k, q0 + 3 * h);
+      const Fe<F> x0 = lds_get<F>(lds, a0_), x2 = lds_get<F>(lds, a2_);
+      Fe<F> t1 = lds_get<F>(lds, a1_), t3 = lds_get<F>(lds, a3_);
+      if (!first) {
+        const Fe<F> twa = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s)) * F::N);
+        t1 = Fd::mul(t1, twa);
+        t3 = Fd::mul(t3, twa);
       }
-      lds_put<F>(lds, p0, Fd::add(x, y));
-      lds_put<F>(lds, p1, Fd::sub(x, y));
+      // level s
+      const Fe<F> b0 = Fd::add_lazy(x0, t1), b1 = Fd::sub_lazy4(x0, t1);
+      Fe<F> u2 = Fd::add_lazy(x2, t3), u3 = Fd::sub_lazy4(x2, t3);
+      // level s+1: pairs (q0, q0+2h) with twiddle index i, (q0+h, q0+3h) with index i+h
+      if (first) {
+        u2 = Fd::carry(u2);                                   // twiddle 1: only normalise for sub_lazy4
+      } else {
+        u2 = Fd::mul(u2, glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s - 1)) * F::N));
+      }
+      u3 = Fd::mul(u3, glb_get_limbs<F>(a.stage + (size_t)((i + h) << (a.kmax - s - 1)) * F::N));
+      lds_put<F>(lds, a0_, Fd::carry(Fd::add_lazy(b0, u2)));
+      lds_put<F>(lds, a2_, Fd::carry(Fd::sub_lazy4(b0, u2)));
+      lds_put<F>(lds, a1_, Fd::carry(Fd::add_lazy(b1, u3)));
+      lds_put<F>(lds, a3_, Fd::carry(Fd::sub_lazy4(b1, u3)));
     }
     __syncthreads();
   }
 
-  // ---- store: optional twist w^(pos*col), optional scale, canonical words out
+  // ---- store: one multiplication (twist or final scale) reduces the lazy value below 2p
   for (uint32_t idx = tid; idx < TILE; idx += T) {
     const uint32_t line = idx & (C - 1), pos = idx >> logC;
     Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
-    if (a.twA) {
+    if (a.twist) {
       const uint64_t col = tile * C + line;
-      const uint64_t e = (uint64_t)pos * col;
-      const Fe<F> ta = glb_get_limbs<F>(a.twA + (size_t)(e >> a.h) * F::N);
-      const Fe<F> tb = glb_get_limbs<F>(a.twB + (size_t)(e & ((1ull << a.h) - 1)) * F::N);
-      x = Fd::mul(x, Fd::mul(ta, tb));
+      x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
+    } else {
+      x = Fd::mul(x, glb_get_limbs<F>(a.scale));
     }
-    if (a.scale) x = Fd::mul(x, glb_get_limbs<F>(a.scale));
     x = Fd::reduce(x);
     uint32_t w[8];
     Fd::to_words(x, w);
@@ -158,8 +195,24 @@ __global__ void pow_table_kernel(uint32_t* out, const uint32_t* base_mult, uint3
     if (bits & 1u) acc = Fd::mul(acc, b);
     b = Fd::mul(b, b);
   }
+  acc = Fd::reduce(acc);   // canonical: the lazy butterflies rely on twiddles < p
 #pragma unroll
   for (int j = 0; j < F::N; ++j) out[(size_t)e * F::N + j] = acc.l[j];
+}
+
+// twist[t * N2 + v] = A[e >> h] * B[e & (2^h - 1)], e = t*v  (w^(t*v) in Montgomery form)
+template <class F>
+__global__ void twist_table_kernel(uint32_t* out, const uint32_t* twA, const uint32_t* twB, uint32_t h,
+                                   uint32_t log_n2, uint64_t n) {
+  using Fd = Field<F>;
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const uint64_t t = idx >> log_n2, v = idx & ((1ull << log_n2) - 1);
+  const uint64_t e = t * v;
+  const Fe<F> r = Fd::reduce(Fd::mul(glb_get_limbs<F>(twA + (size_t)(e >> h) * F::N),
+                                     glb_get_limbs<F>(twB + (size_t)(e & ((1ull << h) - 1)) * F::N)));
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) out[(size_t)idx * F::N + j] = r.l[j];
 }
 
 template <class F>
@@ -182,7 +235,7 @@ int build_domain(Ctx* c, NttDomain& d) {
   std::vector<Job> jobs;
   if (d.kmax >= 1) jobs.push_back({&d.d_stage, pow2k(w, log_n - d.kmax), Fd::one(), 1u << (d.kmax - 1)});
   if (two_pass) {
-    jobs.push_back({&d.d_twA, pow2k(w, d.h), d.inverse ? ninv : Fd::one(), 1u << (log_n - d.h)});
+    jobs.push_back({&d.d_twA, pow2k(w, d.h), Fd::one(), 1u << (log_n - d.h)});
     jobs.push_back({&d.d_twB, w, Fd::one(), 1u << d.h});
   }
   uint32_t* d_tmp = nullptr;
@@ -200,10 +253,22 @@ int build_domain(Ctx* c, NttDomain& d) {
     KZG_HIP(c, hipStreamSynchronize(c->stream));
   }
   KZG_HIP(c, hipFree(d_tmp));
-  if (d.inverse && !two_pass) {
-    KZG_HIP(c, hipMalloc(&d.d_scale, F::N * 4));
-    KZG_HIP(c, hipMemcpy(d.d_scale, ninv.l, F::N * 4, hipMemcpyHostToDevice));
+  if (two_pass) {   // full twist table (one multiplication per element between the passes)
+    const uint32_t k2 = log_n - (log_n + 1) / 2;
+    const uint64_t n = 1ull << log_n;
+    KZG_HIP(c, hipMalloc(&d.d_twist, (size_t)n * F::N * 4));
+    hipLaunchKernelGGL(twist_table_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d.d_twist,
+                       d.d_twA, d.d_twB, d.h, k2, n);
+    KZG_HIP(c, hipGetLastError());
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+    KZG_HIP(c, hipFree(d.d_twA));
+    KZG_HIP(c, hipFree(d.d_twB));
+    d.d_twA = d.d_twB = nullptr;
   }
+  // multiplier of the last pass: Montgomery 1 (forward) or n^-1 (inverse, fft_ff.py:57-58)
+  const Fe<F> last = Fd::reduce(d.inverse ? ninv : Fd::one());
+  KZG_HIP(c, hipMalloc(&d.d_scale, F::N * 4));
+  KZG_HIP(c, hipMemcpy(d.d_scale, last.l, F::N * 4, hipMemcpyHostToDevice));
   return KZG_OK;
 }
 
@@ -228,7 +293,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   };
   if (log_n <= (uint32_t)TILE_LOG) {
     NttPassArgs a{};
-    a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twA = nullptr; a.twB = nullptr;
+    a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.scale = d.d_scale; a.k = log_n; a.logC = 0; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
     a.ld_line = 0; a.ld_pos = 1; a.tile_ld = 0; a.st_line = 0; a.st_pos = 1; a.tile_st = 0;
     a.batch_stride = n;
@@ -242,7 +307,8 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   {  // pass 1: columns of the N1 x N2 matrix, twist by w^(t*v)
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, k2);
     NttPassArgs a{};
-    a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twA = d.d_twA; a.twB = d.d_twB; a.scale = nullptr;
+    a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twist = d.d_twist; a.twist_pitch = N2;
+    a.scale = nullptr;
     a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1;
     a.ld_line = 1; a.ld_pos = N2; a.tile_ld = 1ull << logC;
     a.st_line = 1; a.st_pos = N2; a.tile_st = 1ull << logC;
@@ -253,7 +319,8 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   {  // pass 2: rows; row t, output index b -> out[b*N1 + t]
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k2, k1);
     NttPassArgs a{};
-    a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twA = nullptr; a.twB = nullptr; a.scale = nullptr;
+    a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
+    a.scale = d.d_scale;
     a.k = k2; a.logC = logC; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
     a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
     a.st_line = 1; a.st_pos = N1; a.tile_st = 1ull << logC;
@@ -271,13 +338,13 @@ int ntt_run_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words,
   for (auto& d : c->domains)
     if (d.log_n == log_n && d.inverse == inverse && memcmp(d.w, w_words, 32) == 0) { dom = &d; break; }
   if (!dom) {
-    if (c->domains.size() >= 16) {   // evict least recently used
+    if (c->domains.size() >= 8) {   // evict least recently used
       size_t victim = 0;
       for (size_t i = 1; i < c->domains.size(); ++i)
         if (c->domains[i].last_use < c->domains[victim].last_use) victim = i;
       NttDomain& v = c->domains[victim];
       hipStreamSynchronize(c->stream);
-      hipFree(v.d_stage); hipFree(v.d_twA); hipFree(v.d_twB); hipFree(v.d_scale);
+      hipFree(v.d_stage); hipFree(v.d_twA); hipFree(v.d_twB); hipFree(v.d_scale); hipFree(v.d_twist);
       c->domains.erase(c->domains.begin() + victim);
     }
     NttDomain d;
@@ -302,7 +369,7 @@ int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_w
 
 void ntt_free_domains(Ctx* c) {
   for (auto& d : c->domains) {
-    hipFree(d.d_stage); hipFree(d.d_twA); hipFree(d.d_twB); hipFree(d.d_scale);
+    hipFree(d.d_stage); hipFree(d.d_twA); hipFree(d.d_twB); hipFree(d.d_scale); hipFree(d.d_twist);
   }
   c->domains.clear();
 }

@@ -304,8 +304,10 @@ __global__ void msm_ns_kernel(const uint32_t* bstart, const uint32_t* order, uin
   ns[r] = (bstart[k + 1] - bstart[k] + Win<WB>::SEG - 1) / Win<WB>::SEG;
 }
 
+// At most 2 waves per SIMD: the kernel is ALU-bound and saturates the multiplier with two; the
+// registers left free let the memory-bound prep kernels of the next polynomial co-reside.
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
                                                              const uint32_t* bstart, const uint32_t* order,
                                                              const uint32_t* slice_off, uint32_t* partials) {
   using F = typename C::Fp;
@@ -356,33 +358,59 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* parti
   if (r < NB && g == 0) store_xyzz<C>(buckets, order[r], acc);
 }
 
-// Block-wide sum of `count` bucket-matrix entries v = base_v + e*stride_v (entry v is
-// buckets[v-1]; v = 0 is the empty digit).  blockIdx.y = 0: rows (block b = row b),
-// blockIdx.y = 1: columns.  128 threads: serial part, 6 shuffle levels, LDS across 2 waves.
+// Row and column sums of the bucket matrix (entry v = hi*2^LO + lo is buckets[v-1]; v = 0 is
+// the empty digit), in two steps with every lane busy:
+//   step 1: a lane adds RC_CH entries of one column (blockIdx.y = 0) or one row (= 1) serially;
+//           consecutive lanes touch consecutive buckets.  colpart[chunk][lo], rowpart[hi][chunk].
+//   step 2: RC_L2 lanes fold the partials of one column / row (serial + 2 shuffle levels).
+constexpr uint32_t RC_CH = 32;
+constexpr uint32_t RC_L2 = 4;
+
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_rowcol_kernel(const uint32_t* buckets, uint32_t* rowsum,
-                                                         uint32_t* colsum) {
-  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI, N = C::Fp::N;
-  __shared__ uint32_t xch[4 * N];
-  const bool cols = blockIdx.y == 1;
-  const uint32_t b = blockIdx.x;
-  const uint32_t nseg = cols ? (1u << LO) : (1u << HI);
-  if (b >= nseg) return;                                   // whole block exits together
-  const uint32_t count = cols ? (1u << HI) : (1u << LO);
-  const uint32_t base_v = cols ? b : (b << LO);
-  const uint32_t stride_v = cols ? (1u << LO) : 1u;
+__global__ __launch_bounds__(128) void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
+                                                      uint32_t* rowpart) {
+  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
+  constexpr uint32_t NCHR = (1u << LO) / RC_CH;            // chunks per row (interleaved)
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= Win<WB>::NB / RC_CH) return;
   XYZZ<C> acc = Ec<C>::infinity();
-  for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
-    const uint32_t v = base_v + e * stride_v;
-    if (v) acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
+  if (blockIdx.y == 0) {          // column lo, rows chunk*RC_CH .. +RC_CH-1
+    const uint32_t lo = L & ((1u << LO) - 1), chunk = L >> LO;
+    for (uint32_t e = 0; e < RC_CH; ++e) {
+      const uint32_t v = ((chunk * RC_CH + e) << LO) + lo;
+      if (v) acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
+    }
+    store_xyzz<C>(colpart, L, acc);
+  } else {                        // row hi, columns c, c + NCHR, c + 2*NCHR, ...
+    const uint32_t c = L & (NCHR - 1), hi = L / NCHR;
+    for (uint32_t e = 0; e < RC_CH; ++e) {
+      const uint32_t v = (hi << LO) + e * NCHR + c;
+      if (v) acc = Ec<C>::add(acc, load_xyzz<C>(buckets, v - 1));
+    }
+    store_xyzz<C>(rowpart, L, acc);
+  }
+}
+
+template <class C, int WB>
+__global__ __launch_bounds__(128) void msm_rc2_kernel(const uint32_t* colpart, const uint32_t* rowpart,
+                                                      uint32_t* colsum, uint32_t* rowsum) {
+  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
+  constexpr uint32_t NCHC = (1u << HI) / RC_CH, NCHR = (1u << LO) / RC_CH;
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t vec = gt / RC_L2, g = gt % RC_L2;         // vectors 0..2^LO-1: columns, then rows
+  XYZZ<C> acc = Ec<C>::infinity();
+  const bool is_col = vec < (1u << LO);
+  const uint32_t row = vec - (1u << LO);
+  if (is_col) {
+    for (uint32_t q = g; q < NCHC; q += RC_L2) acc = Ec<C>::add(acc, load_xyzz<C>(colpart, (q << LO) + vec));
+  } else if (row < (1u << HI)) {
+    for (uint32_t q = g; q < NCHR; q += RC_L2) acc = Ec<C>::add(acc, load_xyzz<C>(rowpart, row * NCHR + q));
   }
 #pragma unroll
-  for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
-  if (threadIdx.x == 64) store_xyzz<C>(xch, 0, acc);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    acc = Ec<C>::add(acc, load_xyzz<C>(xch, 0));
-    store_xyzz<C>(cols ? colsum : rowsum, b, acc);
+  for (int m = 1; m < (int)RC_L2; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  if (g == 0) {
+    if (is_col) store_xyzz<C>(colsum, vec, acc);
+    else if (row < (1u << HI)) store_xyzz<C>(rowsum, row, acc);
   }
 }
 
@@ -568,7 +596,7 @@ constexpr int NSLOT = 3;
 
 struct MsmSlot {
   DevBuf keys_a, keys_b, vals_a, vals_b, bstart, lkey_a, lkey_b, lval_a, ns;       // prep
-  DevBuf order, slice_off, partials, buckets, rowsum, colsum, tb;
+  DevBuf order, slice_off, partials, buckets, rowsum, colsum, rowpart, colpart, tb;
   void* h_tb = nullptr;        // pinned host copy of the partial points
   hipEvent_t ev_in = nullptr;  // inputs ready on the context's stream
   hipEvent_t ev_p = nullptr;   // prep done
@@ -597,7 +625,8 @@ void msm_free_work(Ctx* c) {
   for (auto& b : w->sort_tmp) hipFree(b.p);
   for (auto& sl : w->slot) {
     for (DevBuf* b : {&sl.keys_a, &sl.keys_b, &sl.vals_a, &sl.vals_b, &sl.bstart, &sl.lkey_a, &sl.lkey_b, &sl.lval_a,
-                      &sl.ns, &sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.tb})
+                      &sl.ns, &sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.rowpart,
+                      &sl.colpart, &sl.tb})
       hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
     for (hipEvent_t e : {sl.ev_in, sl.ev_p, sl.ev_a, sl.ev_b})
@@ -634,6 +663,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.buckets, (size_t)NB * PT))) return rc;
   if ((rc = ensure_buf(c, sl.rowsum, ((size_t)1 << W::HI) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.colsum, ((size_t)1 << W::LO) * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.rowpart, (size_t)(NB / RC_CH) * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.colpart, (size_t)(NB / RC_CH) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.tb, (size_t)MAX_NPART * PT))) return rc;
   if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
@@ -712,9 +743,12 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   }
   {
     ProfScope ps(c, "msm_reduce", sb);
-    hipLaunchKernelGGL((msm_rowcol_kernel<C, WB>), dim3(1u << W::LO, 2), dim3(128), 0, sb,
-                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.rowsum.p),
-                       static_cast<uint32_t*>(sl.colsum.p));
+    hipLaunchKernelGGL((msm_rc1_kernel<C, WB>), dim3((NB / RC_CH + 127) / 128, 2), dim3(128), 0, sb,
+                       static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.colpart.p),
+                       static_cast<uint32_t*>(sl.rowpart.p));
+    hipLaunchKernelGGL((msm_rc2_kernel<C, WB>), dim3((((1u << W::LO) + (1u << W::HI)) * RC_L2 + 127) / 128),
+                       dim3(128), 0, sb, static_cast<uint32_t*>(sl.colpart.p), static_cast<uint32_t*>(sl.rowpart.p),
+                       static_cast<uint32_t*>(sl.colsum.p), static_cast<uint32_t*>(sl.rowsum.p));
     hipLaunchKernelGGL((msm_planes_kernel<C, WB>), dim3(W::NPART), dim3(64), 0, sb,
                        static_cast<uint32_t*>(sl.rowsum.p), static_cast<uint32_t*>(sl.colsum.p),
                        static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.tb.p));

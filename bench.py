@@ -26,6 +26,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see kzg_snark_amd/_native.py: one HW queue per pipeline stream
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -5,7 +5,13 @@ is visible, the first call raises NativeUnavailable -- loudly, by design."""
 import ctypes
 import os
 
-import numpy as np
+# The commit pipeline runs three internal streams beside the caller's; HIP multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.
+# Must be in the environment before the HIP runtime initialises (import this module -- or set
+# the variable -- before the first torch.cuda / HIP call).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libkzg_mi355x.so")

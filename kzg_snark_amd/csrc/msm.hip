@@ -26,8 +26,10 @@
 //                   sums of the short R and C vectors
 //     7 host        Horner over the ~20 partial points, one inversion to affine
 #include <cstring>
+#include <cstdlib>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 #include "internal.h"
 #include "ec.h"
@@ -304,10 +306,8 @@ __global__ void msm_ns_kernel(const uint32_t* bstart, const uint32_t* order, uin
   ns[r] = (bstart[k + 1] - bstart[k] + Win<WB>::SEG - 1) / Win<WB>::SEG;
 }
 
-// At most 2 waves per SIMD: the kernel is ALU-bound and saturates the multiplier with two; the
-// registers left free let the memory-bound prep kernels of the next polynomial co-reside.
 template <class C, int WB>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
+__global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
                                                              const uint32_t* bstart, const uint32_t* order,
                                                              const uint32_t* slice_off, uint32_t* partials) {
   using F = typename C::Fp;
@@ -669,8 +669,37 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
     if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
-  for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b})
-    if (!*st) KZG_HIP(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+  if (!w->stream_a) {
+    // Space-partition the GPU: the ALU-bound accumulate stream gets most CUs, the memory-bound
+    // prep stream and the latency-bound reduce stream share a small reserved set (3 of every 16
+    // CUs by default = 48 of 256; KZG_MSM_AUX_CUS=<per-16 count>, 0 disables masking).  Free-for-all
+    // sharing starves the prep kernels (measured: 3 ms under contention vs 0.5 ms alone).
+    int per16 = 3;
+    if (const char* e = getenv("KZG_MSM_AUX_CUS")) per16 = atoi(e);
+    hipDeviceProp_t prop;
+    KZG_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount;
+    bool masked = false;
+    if (per16 > 0 && per16 < 16 && ncu >= 32) {
+      const int words = (ncu + 31) / 32;
+      std::vector<uint32_t> aux(words, 0u), mainm(words, 0u);
+      for (int i = 0; i < ncu; ++i) ((i % 16) < per16 ? aux : mainm)[i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(&w->stream_a, words, mainm.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&w->stream_p, words, aux.data()) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&w->stream_b, words, aux.data()) == hipSuccess) {
+        masked = true;
+      } else {
+        for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b}) {
+          if (*st) hipStreamDestroy(*st);
+          *st = nullptr;
+        }
+        (void)hipGetLastError();
+      }
+    }
+    if (!masked)
+      for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b})
+        KZG_HIP(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+  }
   sl.win_bits = WB;
 
   auto* keys_a = static_cast<Key*>(sl.keys_a.p);

@@ -127,6 +127,21 @@ int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const
                     size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
                     uint64_t* eval_out);
 
+/* ---- KZG.open on ONE polynomial set partitioned by coefficient range across GPUs ----------------
+ * Rank g holds coefficients [lo_g, hi_g) of every polynomial (the same ranges for all) and a key
+ * shard.  kzg_open_shard_begin combines the slices (sum xi^(i+1) p_i) and returns the slice
+ * polynomial's value H_g = sum_j c_(lo_g+j) z^j.  The ranks exchange the H_g (one field element
+ * each); rank g's carry is S_(hi_g) = sum_(g' > g) H_g' * z^(lo_g' - hi_g).  kzg_open_shard_finish
+ * appends the carry as one extra top coefficient, scans, and commits the quotient slice:
+ *   first_rank != 0: coefficients S_1 .. S_(hi-1) against key points 0 ..      (eval_out = P(z))
+ *   otherwise      : coefficients S_lo .. S_(hi-1) against key points lo-1 ..   -- the caller's shard
+ *                    must therefore START at global index lo_g - 1 (kzg_srs_generate_range).
+ * The partial points of all ranks add up to the opening proof. */
+int kzg_open_shard_begin(kzg_ctx* ctx, const void* d_polys, const size_t* lens, size_t k, size_t stride,
+                         const uint64_t z[4], const uint64_t xi[4], uint64_t* chunk_eval_out);
+int kzg_open_shard_finish(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t z[4], const uint64_t carry[4],
+                          int first_rank, uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out);
+
 /* ---- measurement hooks (bench.py) -----------------------------------------------------------
  * When enabled, the library brackets its kernels with HIP events on the context's stream.
  * Span names: "ntt_pass", "msm_digits", "msm_sort", "msm_bounds", "msm_accumulate",

@@ -47,6 +47,8 @@ SIGNATURES = {
     "kzg_commit_device_async": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp]),
     "kzg_commit_flush": (ctypes.c_int, [_vp]),
     "kzg_open": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "kzg_open_shard_begin": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp]),
+    "kzg_open_shard_finish": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     "kzg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "kzg_prof_reset": (ctypes.c_int, [_vp]),
     "kzg_prof_read": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -217,6 +219,23 @@ class Context:
         fn = lib().kzg_open_device if device else lib().kzg_open
         self._check(fn(self._h, srs._h, _as_vp(polys), _as_vp(lens_a), k, stride, _as_vp(z_words),
                        _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf), _as_vp(ev)))
+        return out_xy, out_inf, ev
+
+
+    # ---- sharded open (device pointers)
+    def open_shard_begin(self, d_polys, lens, stride, z_words, xi_words):
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        h = np.zeros(4, dtype=np.uint64)
+        self._check(lib().kzg_open_shard_begin(self._h, _as_vp(d_polys), _as_vp(lens_a), len(lens), stride,
+                                               _as_vp(z_words), _as_vp(xi_words), _as_vp(h)))
+        return h
+
+    def open_shard_finish(self, srs, z_words, carry_words, first_rank):
+        out_xy = np.zeros(2 * self.fp_limbs, dtype=np.uint64)
+        out_inf = np.zeros(1, dtype=np.uint8)
+        ev = np.zeros(4, dtype=np.uint64)
+        self._check(lib().kzg_open_shard_finish(self._h, srs._h, _as_vp(z_words), _as_vp(carry_words),
+                                                int(bool(first_rank)), _as_vp(out_xy), _as_vp(out_inf), _as_vp(ev)))
         return out_xy, out_inf, ev
 
 

@@ -288,6 +288,32 @@ int kzg_open(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* polys, const size
   return kzg_open_device(ctx, srs, c->io.p, lens, k, stride, z, xi, out_xy, out_inf, eval_out);
 }
 
+int kzg_open_shard_begin(kzg_ctx* ctx, const void* d_polys, const size_t* lens, size_t k, size_t stride,
+                         const uint64_t z[4], const uint64_t xi[4], uint64_t* chunk_eval_out) {
+  if (!ctx || !z || !xi || !chunk_eval_out || (k && (!lens || !d_polys))) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return open_shard_begin_device(c, static_cast<const uint32_t*>(d_polys), lens, k, stride,
+                                 reinterpret_cast<const uint32_t*>(z), reinterpret_cast<const uint32_t*>(xi),
+                                 chunk_eval_out);
+}
+
+int kzg_open_shard_finish(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t z[4], const uint64_t carry[4],
+                          int first_rank, uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out) {
+  if (!ctx || !srs || !z || !carry || !out_xy || !out_inf) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  uint32_t* d_vec = nullptr;
+  size_t len = 0;
+  uint64_t ev[4];
+  int rc = open_shard_finish_device(c, reinterpret_cast<const uint32_t*>(z), reinterpret_cast<const uint32_t*>(carry),
+                                    first_rank, &d_vec, &len, ev);
+  if (rc) return rc;
+  if (eval_out) memcpy(eval_out, ev, 32);
+  if (len > srs->s->n) return set_err(c, KZG_ERR_DEGREE, "quotient slice longer than the key shard");
+  return commit_device(c, srs->s, d_vec, &len, 1, len ? len : 1, out_xy, out_inf);
+}
+
 int kzg_prof_enable(kzg_ctx* ctx, int on) {
   if (!ctx) return KZG_ERR_ARG;
   ctx->c.prof_on = on != 0;

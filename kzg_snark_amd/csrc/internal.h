@@ -59,6 +59,7 @@ struct Ctx {
   DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
   DevBuf io;              // staging for the host-pointer entry points
   DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
+  size_t open_shard_n = 0;                // slice length between kzg_open_shard_begin / _finish
   void* msm_work = nullptr;               // MsmWork (msm.hip)
   bool prof_on = false;
   std::vector<ProfSpan> prof;

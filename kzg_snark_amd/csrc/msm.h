@@ -33,4 +33,9 @@ int open_quotient_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, si
                          const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out,
                          size_t* quot_len, uint64_t* eval_out);
 
+int open_shard_begin_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                            const uint32_t* z_words, const uint32_t* xi_words, uint64_t* chunk_eval_out);
+int open_shard_finish_device(Ctx* c, const uint32_t* z_words, const uint32_t* carry_words, int first_rank,
+                             uint32_t** d_vec_out, size_t* vec_len, uint64_t* eval_out);
+
 }  // namespace kzg

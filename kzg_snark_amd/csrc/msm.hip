@@ -670,35 +670,17 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
     if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   if (!w->stream_a) {
-    // Space-partition the GPU: the ALU-bound accumulate stream gets most CUs, the memory-bound
-    // prep stream and the latency-bound reduce stream share a small reserved set (3 of every 16
-    // CUs by default = 48 of 256; KZG_MSM_AUX_CUS=<per-16 count>, 0 disables masking).  Free-for-all
-    // sharing starves the prep kernels (measured: 3 ms under contention vs 0.5 ms alone).
-    int per16 = 3;
-    if (const char* e = getenv("KZG_MSM_AUX_CUS")) per16 = atoi(e);
-    hipDeviceProp_t prop;
-    KZG_HIP(c, hipGetDeviceProperties(&prop, c->device));
-    const int ncu = prop.multiProcessorCount;
-    bool masked = false;
-    if (per16 > 0 && per16 < 16 && ncu >= 32) {
-      const int words = (ncu + 31) / 32;
-      std::vector<uint32_t> aux(words, 0u), mainm(words, 0u);
-      for (int i = 0; i < ncu; ++i) ((i % 16) < per16 ? aux : mainm)[i / 32] |= 1u << (i % 32);
-      if (hipExtStreamCreateWithCUMask(&w->stream_a, words, mainm.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&w->stream_p, words, aux.data()) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&w->stream_b, words, aux.data()) == hipSuccess) {
-        masked = true;
-      } else {
-        for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b}) {
-          if (*st) hipStreamDestroy(*st);
-          *st = nullptr;
-        }
-        (void)hipGetLastError();
-      }
-    }
-    if (!masked)
-      for (hipStream_t* st : {&w->stream_p, &w->stream_a, &w->stream_b})
-        KZG_HIP(c, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    // prep and reduce kernels are short and memory- / latency-bound; the accumulate kernel fills the
+    // machine for milliseconds.  High priority for the former gets them dispatched as accumulate
+    // workgroups retire instead of starving behind its queue.  (A CU-masked partition was tried
+    // and was slower on this device; KZG_MSM_PRIO=0 turns priorities off.)
+    int lo_prio = 0, hi_prio = 0;
+    KZG_HIP(c, hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+    const char* e = getenv("KZG_MSM_PRIO");
+    const bool use_prio = !(e && atoi(e) == 0) && lo_prio != hi_prio;
+    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_a, hipStreamNonBlocking, use_prio ? lo_prio : 0));
+    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_p, hipStreamNonBlocking, use_prio ? hi_prio : 0));
+    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_b, hipStreamNonBlocking, use_prio ? hi_prio : 0));
   }
   sl.win_bits = WB;
 

@@ -141,10 +141,13 @@ __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size
   if (acc) atomicOr(flag, 1u);
 }
 
+// Buffer layout of poly_tmp[0] (canonical words, 8 per element), cap = n + 1:
+//   comb[0 .. cap)   combined polynomial (+ one optional appended top coefficient)
+//   eval             S_0
+//   quot[0 .. cap)   S_1, S_2, ...        => [eval, quot...] is the contiguous vector S_0, S_1, ...
 template <class F>
-int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
-                    const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out, size_t* quot_len,
-                    uint64_t* eval_out) {
+int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                   const uint32_t* xi_words, size_t* n_out) {
   using Fd = Field<F>;
   if (k > MAXK) return set_err(c, KZG_ERR_ARG, "kzg_open: more than 64 polynomials");
   size_t n = 0;
@@ -152,50 +155,25 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
     if (lens[i] > stride) return set_err(c, KZG_ERR_ARG, "kzg_open: lens[i] > stride");
     n = std::max(n, lens[i]);
   }
-  memset(eval_out, 0, 32);
-  *quot_len = 0;
-  *d_quot_out = nullptr;
-  if (n == 0) return KZG_OK;     // all polynomials zero: witness 0, evaluation 0
-  if (n >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_open: polynomial too long");
-
-  // levels: m[0] = n, m[l+1] = ceil(m[l]/LC) until <= LC
-  std::vector<uint32_t> m{(uint32_t)n};
-  while (m.back() > LC) m.push_back((m.back() + LC - 1) / LC);
-  const size_t nl = m.size();
-
-  // host scalars: xi^(i+1) and z^(LC^l), Montgomery limbs
+  *n_out = n;
+  if (n == 0) return KZG_OK;
+  if (n >= (1ull << 31) - 1) return set_err(c, KZG_ERR_ARG, "kzg_open: polynomial too long");
   const Fe<F> xi = Fd::to_mont(Fd::from_words(xi_words));
-  const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
-  std::vector<uint32_t> hs((k + nl) * F::N);
+  std::vector<uint32_t> hs(k * F::N);
   Fe<F> xp = Fd::one();
   for (size_t i = 0; i < k; ++i) {
     xp = Fd::mul(xp, xi);
     memcpy(&hs[i * F::N], xp.l, F::N * 4);
   }
-  Fe<F> zp = z;
-  for (size_t l = 0; l < nl; ++l) {
-    memcpy(&hs[(k + l) * F::N], zp.l, F::N * 4);
-    for (int q = 0; q < 5; ++q) zp = Fd::mul(zp, zp);     // ^32 = ^LC
-  }
-  static_assert(LC == 32, "zp update assumes LC = 2^5");
-
-  // device buffers: [0] combined + quotient + eval (words), [1] scalars, [2] level values h, [3] suffix values S
-  size_t hl_total = 0, sl_total = 0;
-  for (size_t l = 1; l < nl; ++l) { hl_total += m[l]; sl_total += m[l] + 1; }
   int rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * n + 1) * 32))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[1], hs.size() * 4))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[2], (hl_total + 1) * F::N * 4))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[3], (sl_total + 2) * F::N * 4))) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * (n + 1) + 1) * 32))) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[1], (k + 16) * F::N * 4))) return rc;
   uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
-  uint32_t* d_quot = d_comb + n * 8;
-  uint32_t* d_eval = d_comb + 2 * n * 8;
   uint32_t* d_sc = static_cast<uint32_t*>(c->poly_tmp[1].p);
-  uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
-  uint32_t* d_S = static_cast<uint32_t*>(c->poly_tmp[3].p);
-  KZG_HIP(c, hipMemcpyAsync(d_sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
-  KZG_HIP(c, hipStreamSynchronize(c->stream));     // hs is a local vector
-
+  if (k) {
+    KZG_HIP(c, hipMemcpyAsync(d_sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));     // hs is a local vector
+  }
   ProfScope ps(c, "open_poly");
   LincombArgs la{};
   la.polys = d_polys; la.stride = stride; la.k = (uint32_t)k;
@@ -203,8 +181,40 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
   hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_sc, d_comb,
                      (uint32_t)n);
   KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
 
-  auto zpow = [&](size_t l) { return d_sc + (k + l) * F::N; };
+// Suffix-Horner scan of comb[0 .. n) (n >= 1) at z: eval <- S_0, quot[j-1] <- S_j.  `cap` fixes the layout.
+template <class F>
+int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out) {
+  using Fd = Field<F>;
+  std::vector<uint32_t> m{(uint32_t)n};
+  while (m.back() > LC) m.push_back((m.back() + LC - 1) / LC);
+  const size_t nl = m.size();
+  const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
+  std::vector<uint32_t> hs(nl * F::N);
+  Fe<F> zp = z;
+  for (size_t l = 0; l < nl; ++l) {
+    memcpy(&hs[l * F::N], zp.l, F::N * 4);
+    for (int q = 0; q < 5; ++q) zp = Fd::mul(zp, zp);     // ^32 = ^LC
+  }
+  static_assert(LC == 32, "zp update assumes LC = 2^5");
+  size_t hl_total = 0, sl_total = 0;
+  for (size_t l = 1; l < nl; ++l) { hl_total += m[l]; sl_total += m[l] + 1; }
+  int rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[2], (hl_total + 1) * F::N * 4))) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[3], (sl_total + 2 + nl) * F::N * 4))) return rc;
+  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
+  uint32_t* d_eval = d_comb + cap * 8;
+  uint32_t* d_quot = d_eval + 8;
+  uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
+  uint32_t* d_S = static_cast<uint32_t*>(c->poly_tmp[3].p);
+  uint32_t* d_zp = d_S + (sl_total + 2) * F::N;           // z^(LC^l) limbs behind the suffix arrays
+  KZG_HIP(c, hipMemcpyAsync(d_zp, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+
+  ProfScope ps(c, "open_poly");
+  auto zpow = [&](size_t l) { return d_zp + l * F::N; };
   std::vector<uint32_t*> hptr(nl, nullptr), sptr(nl, nullptr);
   {
     uint32_t* hp = d_h; uint32_t* sp = d_S;
@@ -216,16 +226,13 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
     hipLaunchKernelGGL((chunk_fill_kernel<F, true>), dim3(1), dim3(64), 0, c->stream, d_comb, m[0], zpow(0), d_S,
                        (uint32_t*)nullptr, d_quot, d_eval);
   } else {
-    // bottom-up
     hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, d_comb, m[0],
                        zpow(0), hptr[1]);
     for (size_t l = 1; l + 1 < nl; ++l)
       hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
                          m[l], zpow(l), hptr[l + 1]);
-    // top
     hipLaunchKernelGGL(top_suffix_kernel<F>, dim3(1), dim3(64), 0, c->stream, hptr[nl - 1], m[nl - 1], zpow(nl - 1),
                        sptr[nl - 1]);
-    // top-down
     for (size_t l = nl - 2; l >= 1; --l)
       hipLaunchKernelGGL((chunk_fill_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
                          m[l], zpow(l), sptr[l + 1], sptr[l], (uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -235,8 +242,62 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
   KZG_HIP(c, hipStreamSynchronize(c->stream));
-  *d_quot_out = d_quot;
+  return KZG_OK;
+}
+
+template <class F>
+int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                    const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out, size_t* quot_len,
+                    uint64_t* eval_out) {
+  memset(eval_out, 0, 32);
+  *quot_len = 0;
+  *d_quot_out = nullptr;
+  size_t n = 0;
+  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n);
+  if (rc) return rc;
+  if (n == 0) return KZG_OK;     // all polynomials zero: witness 0, evaluation 0
+  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, eval_out))) return rc;
+  *d_quot_out = static_cast<uint32_t*>(c->poly_tmp[0].p) + (n + 1) * 8 + 8;
   *quot_len = n - 1;
+  return KZG_OK;
+}
+
+// Sharded open, step 1: combine this rank's coefficient slices and evaluate the slice polynomial
+// (local indexing) at z.
+template <class F>
+int open_shard_begin_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                       const uint32_t* z_words, const uint32_t* xi_words, uint64_t* chunk_eval_out) {
+  memset(chunk_eval_out, 0, 32);
+  size_t n = 0;
+  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n);
+  if (rc) return rc;
+  c->open_shard_n = n;
+  if (n == 0) return KZG_OK;
+  return open_scan_t<F>(c, n, n + 1, z_words, chunk_eval_out);
+}
+
+// step 2: with the carry S_hi of the ranks above appended as an extra top coefficient the scan
+// yields S_lo .. S_(hi-1) exactly (linearity).  Returns the vector to commit.
+template <class F>
+int open_shard_finish_t(Ctx* c, const uint32_t* z_words, const uint32_t* carry_words, int first_rank,
+                        uint32_t** d_vec_out, size_t* vec_len, uint64_t* eval_out) {
+  memset(eval_out, 0, 32);
+  *d_vec_out = nullptr;
+  *vec_len = 0;
+  const size_t n = c->open_shard_n;
+  if (n == 0) return KZG_OK;
+  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
+  KZG_HIP(c, hipMemcpyAsync(d_comb + n * 8, carry_words, 32, hipMemcpyHostToDevice, c->stream));
+  int rc = open_scan_t<F>(c, n + 1, n + 1, z_words, eval_out);
+  if (rc) return rc;
+  uint32_t* d_eval = d_comb + (n + 1) * 8;
+  if (first_rank) {            // S_0 is the evaluation; the quotient slice is S_1 .. S_(n-1)
+    *d_vec_out = d_eval + 8;
+    *vec_len = n - 1;
+  } else {                     // S_lo is the quotient coefficient lo-1: commit S_lo .. S_(hi-1)
+    *d_vec_out = d_eval;
+    *vec_len = n;
+  }
   return KZG_OK;
 }
 
@@ -248,6 +309,17 @@ int open_quotient_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, si
   return c->curve == 0
              ? open_quotient_t<BnFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len, eval_out)
              : open_quotient_t<BlsFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len, eval_out);
+}
+
+int open_shard_begin_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                            const uint32_t* z_words, const uint32_t* xi_words, uint64_t* chunk_eval_out) {
+  return c->curve == 0 ? open_shard_begin_t<BnFr>(c, d_polys, lens, k, stride, z_words, xi_words, chunk_eval_out)
+                       : open_shard_begin_t<BlsFr>(c, d_polys, lens, k, stride, z_words, xi_words, chunk_eval_out);
+}
+int open_shard_finish_device(Ctx* c, const uint32_t* z_words, const uint32_t* carry_words, int first_rank,
+                             uint32_t** d_vec_out, size_t* vec_len, uint64_t* eval_out) {
+  return c->curve == 0 ? open_shard_finish_t<BnFr>(c, z_words, carry_words, first_rank, d_vec_out, vec_len, eval_out)
+                       : open_shard_finish_t<BlsFr>(c, z_words, carry_words, first_rank, d_vec_out, vec_len, eval_out);
 }
 
 // true iff any of the elements [from, to) of a canonical-word array is non-zero

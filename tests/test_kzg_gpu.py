@@ -241,3 +241,68 @@ def test_reference_selftest_recipe(kzgs, curve):
     bad[1][0] = bad[1][0] + 1
     assert not kzg.check(rk, commitments_list[1], z_list[1], bad[1], proof_list[1], xi_list[1])
     assert not kzg.batch_check(rk, commitments_list, z_list, bad, proof_list, xi_list)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_sharded_open_and_commit_by_coefficient_range(native, kzgs, curve):
+    """Range-mode sharding rehearsed on one GPU: the 'ranks' run one after the
+    other; key shards come from kzg_srs_generate_range; partial points are added on the host.
+    Must equal the unsharded open / commit (and the trapdoor identity)."""
+    import torch
+    from kzg_snark_amd.sharding import range_of
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    ctx = native.get_context(curve)
+    rng = random.Random(31)
+    n, world = 1000, 3
+    tau = rng.randrange(cv.r)
+    lens = [n, 700, 333]                                  # ragged: later polynomials end inside a shard
+    polys = [[rng.randrange(cv.r) for _ in range(m)] for m in lens]
+    z, xi = rng.randrange(cv.r), rng.randrange(cv.r)
+    zw, xw, tw = native.int_to_words(z), native.int_to_words(xi), native.int_to_words(tau)
+    L = ctx.fp_limbs
+
+    def to_pt(xy, inf):
+        if inf:
+            return kzg.Z1
+        v = native.limbs_to_ints(xy.reshape(2, L))
+        return (v[0], v[1], 1)
+
+    ranges = [range_of(g, world, n) for g in range(world)]
+    # phase 1 on every rank: slice evaluation H_g
+    dev_slices, H = [], []
+    for lo, hi in ranges:
+        arr = np.zeros((len(polys), hi - lo, 4), dtype=np.uint64)
+        sl_lens = []
+        for i, p in enumerate(polys):
+            part = p[lo:hi]
+            sl_lens.append(len(part))
+            if part:
+                arr[i, :len(part)] = native.ints_to_limbs(part)
+        t = torch.from_numpy(arr.view(np.int64)).to("cuda:0")
+        dev_slices.append((t, sl_lens))
+        h = ctx.open_shard_begin(t.data_ptr(), sl_lens, hi - lo, zw, xw)
+        H.append(native.limbs_to_ints(h.reshape(1, 4))[0])
+    # exchange (host): carry_g = sum_{g' > g} H_g' * z^(lo_g' - hi_g)
+    carries = []
+    for g, (lo, hi) in enumerate(ranges):
+        carries.append(sum(H[g2] * pow(z, ranges[g2][0] - hi, cv.r) for g2 in range(g + 1, world)) % cv.r)
+    # phase 2 on every rank
+    proof, commit_sum, ev0 = kzg.Z1, kzg.Z1, None
+    for g, (lo, hi) in enumerate(ranges):
+        t, sl_lens = dev_slices[g]
+        ctx.open_shard_begin(t.data_ptr(), sl_lens, hi - lo, zw, xw)      # a context holds one slice at a time
+        start = 0 if g == 0 else lo - 1
+        shard = ctx.srs_generate(tw, hi - 1 - start, start=start)
+        xy, inf, ev = ctx.open_shard_finish(shard, zw, native.int_to_words(carries[g]), g == 0)
+        proof = kzg.add(proof, to_pt(xy, inf[0]))
+        if g == 0:
+            ev0 = native.limbs_to_ints(ev.reshape(1, 4))[0]
+        # range-mode commit of the first polynomial with a shard starting at lo
+        cshard = ctx.srs_generate(tw, hi - lo, start=lo)
+        cxy, cinf = ctx.commit_device(cshard, t.data_ptr(), [hi - lo], hi - lo)
+        commit_sum = kzg.add(commit_sum, to_pt(cxy[0], cinf[0]))
+    want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
+    assert (proof[0], proof[1]) == want
+    assert ev0 == O.poly_eval(O.combine(polys, xi, cv.r), z, cv.r)
+    assert (commit_sum[0], commit_sum[1]) == O.normalize(O.commit_trapdoor(polys[0], tau, cv), cv)

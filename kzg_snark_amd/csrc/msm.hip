@@ -695,7 +695,9 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   auto* bstart = static_cast<uint32_t*>(sl.bstart.p);
   auto* order = static_cast<uint32_t*>(sl.order.p);
   auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
-  hipStream_t sp = w->stream_p, sa = w->stream_a, sb = w->stream_b;
+  // KZG_MSM_STREAMS=2: prep shares the accumulate stream (only the reduce stage overlaps)
+  static const bool two_streams = [] { const char* e = getenv("KZG_MSM_STREAMS"); return e && atoi(e) == 2; }();
+  hipStream_t sa = w->stream_a, sb = w->stream_b, sp = two_streams ? sa : w->stream_p;
 
   constexpr unsigned SORT_BITS = WB <= 16 ? 16 : WB;
   size_t t1 = 0, t2 = 0, t3 = 0;

@@ -64,6 +64,25 @@ class DistributedCommitter:
                 out[i] = tuple(pt)
         return out
 
+    def open_range(self, begin_fn, finish_fn, z, modulus, n_total):
+        """KZG.open of polynomials partitioned by coefficient range (kzg.py:122-159, sharded).
+
+        begin_fn() -> int H_g: value at z of this rank's combined slice polynomial, local indexing
+                      (kzg_open_shard_begin);
+        finish_fn(carry, first_rank) -> (partial proof point, P(z) or None)   (kzg_open_shard_finish).
+        One exchange of a field element per rank, one of a point per rank.  Returns (proof, P(z))."""
+        world, rank = self.world, self.rank
+        H = self._all_gather(int(begin_fn()))
+        lo_hi = [range_of(g, world, n_total) for g in range(world)]
+        hi = lo_hi[rank][1]
+        carry = sum(H[g] * pow(z, lo_hi[g][0] - hi, modulus) for g in range(rank + 1, world)) % modulus
+        part, ev = finish_fn(carry, rank == 0)
+        acc = self.zero
+        got = self._all_gather((tuple(part), ev))
+        for pt, _ in got:
+            acc = self.add_fn(acc, tuple(pt))
+        return acc, got[0][1]
+
     def commit_range(self, local_coeffs):
         """local_coeffs: this rank's contiguous slice of ONE polynomial (its SRS shard is what
         commit_fn commits against).  Returns the commitment to the whole polynomial on every rank."""

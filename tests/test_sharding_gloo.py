@@ -53,6 +53,34 @@ def _worker(rank, world, port, q):
         got = dc2.commit_range(p[lo:hi])
         assert got == to_pt(O.commit(full_ck, [p], cv)[0]), "range mode"
         assert got == to_pt(O.commit_trapdoor(p, tau, cv))
+
+        # range-mode open: slice evaluation, carry exchange, quotient slice against a key shard that
+        # starts at lo - 1 (the oracle stands in for kzg_open_shard_begin / _finish)
+        r = cv.r
+        polys3 = [[rng.randrange(r) for _ in range(m)] for m in (n, 9, 4)]
+        z, xi = rng.randrange(r), rng.randrange(r)
+        comb = O.combine(polys3, xi, r) + [0] * n
+        comb = comb[:n]
+        local = comb[lo:hi]
+
+        def begin():
+            return O.poly_eval(local, z, r)
+
+        def finish(carry, first):
+            ext = local + [carry]
+            S = [0] * (len(ext) + 1)
+            for j in range(len(ext) - 1, -1, -1):
+                S[j] = (ext[j] + z * S[j + 1]) % r
+            if first:
+                vec, start, ev = S[1:len(local)], 0, S[0]
+            else:
+                vec, start, ev = S[0:len(local)], lo - 1, None
+            key = full_ck[start:start + len(vec)]
+            return to_pt(O.commit(key, [vec], cv)[0]) if vec else (1, 1, 0), ev
+
+        proof, ev = dc2.open_range(begin, finish, z, r, n)
+        want, pz = O.open_(full_ck, polys3, z, xi, cv)
+        assert proof == to_pt(want) and ev == pz, "range-mode open"
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))

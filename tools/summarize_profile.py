@@ -14,6 +14,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4     # transforms per ntt_pass launch in bench.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
@@ -61,7 +62,8 @@ out = {
               "read bytes = 2 x FETCH_SIZE KiB x 1024 per MI355X_MICROARCH.md, gfx950 correction)",
     "msm_accumulate_kernel": traffic("msm_accumulate_kernel"),
     "ntt_pass_kernel_per_launch": traffic("ntt_pass_kernel"),
-    "ntt_pass_kernel_per_transform": 2 * traffic("ntt_pass_kernel"),
+    "ntt_batch_per_launch": batch,
+    "ntt_pass_kernel_per_transform": 2 * traffic("ntt_pass_kernel") / batch,
 }
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "trace_bench.log"), os.path.join(dst, f"{tag}_bench_under_rocprof.log"))

@@ -203,11 +203,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x14 limbs (381-bit Fp) / u32x9 limbs (255-bit Fr), integer",
+            "dtype": "integer: 13x30-bit limbs in u32 (381-bit Fp), 9x29-bit limbs (255-bit Fr), 64-bit multiply-add",
             "data": "synthetic",
             "config": {"workload": f"degree-2^{log_n} INTT + KZG commit, {args.curve}, 2^{log_n}-point SRS, "
                                    f"uniform Fr scalars, batch of {B} polynomials per GPU per step",
-                       "log_n": log_n, "curve": args.curve, "batch": B, "window_bits": 16,
+                       "log_n": log_n, "curve": args.curve, "batch": B, "window_bits": 20 if n >= (1 << 18) else 16,
                        "sharding": "independent polynomials per rank, replicated SRS"},
             "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
             "ntt_ms": ntt_per_transform_s * 1e3,

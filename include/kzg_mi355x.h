@@ -80,6 +80,20 @@ int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], i
 int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                    uint32_t batch);
 
+/* The two local halves of the multi-GPU four-step transform of n = 2^log_n = N1*N2 elements
+ * (N1 = 2^ceil(log_n/2)); kzg_snark_amd/sharding.py exchanges the data between them with
+ * all-to-all transposes.  Requires log_n > 12.
+ *   columns: d_data is an [N1][n_cols] row-major matrix holding global columns col_base ..
+ *            col_base+n_cols-1 of the N1 x N2 view; transformed in place down the columns and
+ *            multiplied by the twist w^(row * global column).
+ *   rows:    d_data is an [n_rows][N2] matrix (n_rows rows of the twisted matrix); transformed in
+ *            place along the rows, natural order, and scaled (by n^-1 when inverse).
+ * n_cols / n_rows: powers of two. */
+int kzg_ntt_columns_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                           uint64_t n_cols, uint64_t col_base);
+int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                        uint64_t n_rows);
+
 /* ---- commitment key: the `ck` list of KZG.setup / KZG.commit (kzg.py:56-78, 80) ------
  * kzg_srs_load_g1 uploads n affine G1 points (xy: n x 2*FP_LIMBS limbs; inf: n flag bytes or
  * NULL) and expands them into the engine's device table (msm.hip).  Points are checked to be

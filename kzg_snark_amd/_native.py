@@ -36,6 +36,9 @@ SIGNATURES = {
     "kzg_ctx_synchronize": (ctypes.c_int, [_vp]),
     "kzg_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int]),
     "kzg_ntt_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint32]),
+    "kzg_ntt_columns_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
+                                              ctypes.c_uint64]),
+    "kzg_ntt_rows_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64]),
     "kzg_srs_load_g1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "kzg_srs_free": (None, [_vp]),
     "kzg_srs_size": (ctypes.c_size_t, [_vp]),
@@ -163,6 +166,14 @@ class Context:
     def ntt_device(self, d_ptr, log_n, w_words, inverse, batch=1):
         self._check(lib().kzg_ntt_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
                                          int(bool(inverse)), batch))
+
+    def ntt_columns_device(self, d_ptr, log_n, w_words, inverse, n_cols, col_base):
+        self._check(lib().kzg_ntt_columns_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
+                                                 int(bool(inverse)), n_cols, col_base))
+
+    def ntt_rows_device(self, d_ptr, log_n, w_words, inverse, n_rows):
+        self._check(lib().kzg_ntt_rows_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
+                                              int(bool(inverse)), n_rows))
 
     # ---- SRS
     def srs_load_g1(self, xy, inf=None):

@@ -153,6 +153,24 @@ int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[
                         inverse ? 1 : 0, batch);
 }
 
+int kzg_ntt_columns_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                           uint64_t n_cols, uint64_t col_base) {
+  if (!ctx || !d_data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return ntt_partial_device(c, static_cast<uint32_t*>(d_data), log_n, reinterpret_cast<const uint32_t*>(w),
+                            inverse ? 1 : 0, 0, n_cols, col_base);
+}
+
+int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                        uint64_t n_rows) {
+  if (!ctx || !d_data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return ntt_partial_device(c, static_cast<uint32_t*>(d_data), log_n, reinterpret_cast<const uint32_t*>(w),
+                            inverse ? 1 : 0, 1, n_rows, 0);
+}
+
 int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], int inverse) {
   if (!ctx || !data || !w) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;

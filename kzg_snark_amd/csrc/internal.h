@@ -88,6 +88,8 @@ int ensure_buf(Ctx* c, DevBuf& b, size_t bytes);
 // ntt.hip
 int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse,
                    uint32_t batch);
+int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
+                       uint64_t count, uint64_t col_base);
 void ntt_free_domains(Ctx* c);
 
 }  // namespace kzg

@@ -56,6 +56,8 @@ struct NttPassArgs {
   uint32_t kmax;
   uint32_t h;              // twist split
   uint32_t c_fast_load;    // consecutive threads walk lines first when loading
+  uint32_t c_fast_store;   // ... and when storing
+  uint64_t col_base;       // global index of this matrix's first column (distributed column pass)
   uint64_t ld_line, ld_pos, tile_ld;
   uint64_t st_line, st_pos, tile_st;
   uint64_t batch_stride;   // elements between transforms of a batch (blockIdx.y)
@@ -166,10 +168,12 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
 
   // ---- store: one multiplication (twist or final scale) reduces the lazy value below 2p
   for (uint32_t idx = tid; idx < TILE; idx += T) {
-    const uint32_t line = idx & (C - 1), pos = idx >> logC;
+    uint32_t line, pos;
+    if (a.c_fast_store) { line = idx & (C - 1); pos = idx >> logC; }
+    else                { pos = idx & (LEN - 1); line = idx >> k; }
     Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
     if (a.twist) {
-      const uint64_t col = tile * C + line;
+      const uint64_t col = a.col_base + tile * C + line;
       x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
     } else {
       x = Fd::mul(x, glb_get_limbs<F>(a.scale));
@@ -295,6 +299,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     NttPassArgs a{};
     a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.scale = d.d_scale; a.k = log_n; a.logC = 0; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
+    a.c_fast_store = 1; a.col_base = 0;
     a.ld_line = 0; a.ld_pos = 1; a.tile_ld = 0; a.st_line = 0; a.st_pos = 1; a.tile_st = 0;
     a.batch_stride = n;
     return launch(a, 1);
@@ -309,7 +314,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     NttPassArgs a{};
     a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twist = d.d_twist; a.twist_pitch = N2;
     a.scale = nullptr;
-    a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1;
+    a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1; a.c_fast_store = 1; a.col_base = 0;
     a.ld_line = 1; a.ld_pos = N2; a.tile_ld = 1ull << logC;
     a.st_line = 1; a.st_pos = N2; a.tile_st = 1ull << logC;
     a.batch_stride = n;
@@ -321,7 +326,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     NttPassArgs a{};
     a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.scale = d.d_scale;
-    a.k = k2; a.logC = logC; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
+    a.k = k2; a.logC = logC; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0; a.c_fast_store = 1; a.col_base = 0;
     a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
     a.st_line = 1; a.st_pos = N1; a.tile_st = 1ull << logC;
     a.batch_stride = n;
@@ -332,8 +337,70 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
 }
 
 template <class F>
+int get_domain(Ctx* c, uint32_t log_n, const uint32_t* w_words, int inverse, NttDomain** out);
+
+// Distributed four-step NTT, local halves (kzg_snark_amd/sharding.py moves the data between them):
+//   columns: in-place N1-point transforms down the n_cols columns of an [N1][n_cols] matrix whose
+//            first column is global column col_base, followed by the twist w^(t * global column);
+//   rows:    in-place N2-point transforms along the n_rows rows of an [n_rows][N2] matrix, natural
+//            order in and out, followed by the final scale (1, or n^-1 for the inverse transform).
+template <class F>
+int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
+                  uint64_t count, uint64_t col_base) {
+  if (log_n <= (uint32_t)TILE_LOG) return set_err(c, KZG_ERR_ARG, "distributed NTT needs log_n > 12");
+  const uint32_t k1 = (log_n + 1) / 2, k2 = log_n - k1;
+  const uint64_t N1 = 1ull << k1, N2 = 1ull << k2;
+  if (count == 0 || (count & (count - 1))) return set_err(c, KZG_ERR_ARG, "row/column count must be a power of two");
+  if (rows_pass ? count > N1 : (col_base + count > N2)) return set_err(c, KZG_ERR_ARG, "row/column range");
+  NttDomain* dom = nullptr;
+  int rc = get_domain<F>(c, log_n, w_words, inverse, &dom);
+  if (rc) return rc;
+  uint32_t lc = 0;
+  while ((1ull << (lc + 1)) <= count) ++lc;
+  NttPassArgs a{};
+  a.src = d_data; a.dst = d_data; a.stage = dom->d_stage; a.kmax = dom->kmax; a.h = 0; a.batch_stride = 0;
+  uint64_t tiles;
+  if (!rows_pass) {
+    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, lc);
+    a.twist = dom->d_twist; a.twist_pitch = N2; a.scale = nullptr; a.col_base = col_base;
+    a.k = k1; a.logC = logC; a.c_fast_load = 1; a.c_fast_store = 1;
+    a.ld_line = 1; a.ld_pos = count; a.tile_ld = 1ull << logC;
+    a.st_line = 1; a.st_pos = count; a.tile_st = 1ull << logC;
+    tiles = count >> logC;
+  } else {
+    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k2, lc);
+    a.twist = nullptr; a.twist_pitch = 0; a.scale = dom->d_scale; a.col_base = 0;
+    a.k = k2; a.logC = logC; a.c_fast_load = 0; a.c_fast_store = 0;
+    a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
+    a.st_line = N2; a.st_pos = 1; a.tile_st = N2 << logC;
+    tiles = count >> logC;
+  }
+  const uint32_t tile_elems = 1u << (a.k + a.logC);
+  const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2));
+  const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    lds_attr_set = true;
+  }
+  ProfScope ps(c, "ntt_pass");
+  hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, 1), dim3(threads), lds_bytes, c->stream, a);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
 int ntt_run_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, uint32_t batch) {
   if (log_n == 0 || batch == 0) return KZG_OK;   // n == 1: fft_ff.py:16-17 returns the input; 1^-1 = 1
+  NttDomain* dom = nullptr;
+  int rc = get_domain<F>(c, log_n, w_words, inverse, &dom);
+  if (rc) return rc;
+  return launch_passes<F>(c, *dom, d_data, batch);
+}
+
+template <class F>
+int get_domain(Ctx* c, uint32_t log_n, const uint32_t* w_words, int inverse, NttDomain** out) {
   NttDomain* dom = nullptr;
   for (auto& d : c->domains)
     if (d.log_n == log_n && d.inverse == inverse && memcmp(d.w, w_words, 32) == 0) { dom = &d; break; }
@@ -356,7 +423,8 @@ int ntt_run_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words,
     dom = &c->domains.back();
   }
   dom->last_use = ++c->tick;
-  return launch_passes<F>(c, *dom, d_data, batch);
+  *out = dom;
+  return KZG_OK;
 }
 
 }  // namespace
@@ -365,6 +433,13 @@ int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_w
   if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");
   if (c->curve == 0) return ntt_run_t<BnFr>(c, d_data, log_n, w_words, inverse, batch);
   return ntt_run_t<BlsFr>(c, d_data, log_n, w_words, inverse, batch);
+}
+
+int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
+                       uint64_t count, uint64_t col_base) {
+  if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");
+  return c->curve == 0 ? ntt_partial_t<BnFr>(c, d_data, log_n, w_words, inverse, rows_pass, count, col_base)
+                       : ntt_partial_t<BlsFr>(c, d_data, log_n, w_words, inverse, rows_pass, count, col_base);
 }
 
 void ntt_free_domains(Ctx* c) {

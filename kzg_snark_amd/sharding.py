@@ -91,3 +91,80 @@ class DistributedCommitter:
         for pt in self._all_gather(tuple(part)):
             acc = self.add_fn(acc, tuple(pt))
         return acc
+
+
+class DistributedNTT:
+    """Four-step NTT / INTT of n = 2^log_n = N1*N2 elements sharded over G ranks by contiguous
+    index range (natural order in, natural order out), G | N1 and G | N2:
+
+        all-to-all   rows of the N1 x N2 view  ->  whole columns per rank
+        local        column transforms (length N1) + twist w^(t*v)        ops.columns(M, col_base)
+        all-to-all   back to whole rows per rank
+        local        row transforms (length N2) + final scale             ops.rows(T)
+        all-to-all   row t, index b  ->  position b*N1 + t of the natural-order result
+
+    Each all-to-all moves 1/G of the shard to every peer -- one xGMI link per peer, all links
+    driven at once (it is per-link bound, so no ring).  The local halves are injected: the GPU
+    passes (GpuNttOps -> kzg_ntt_columns_device / kzg_ntt_rows_device) in production, the oracle in
+    the gloo tests.  Tensors are int64 [.., 4] views of canonical Fr elements."""
+
+    def __init__(self, ops, group=None, exchange=None):
+        self.ops = ops
+        self.group = group
+        self._exchange = exchange
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def exchange(self, send):
+        """send[h] goes to rank h; returns recv with recv[h] = what rank h sent to us."""
+        if self._exchange is not None:
+            return self._exchange(send)
+        if self.world == 1:
+            return send
+        import torch
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send.contiguous(), group=self.group)
+        return recv
+
+    def transform(self, x_local, log_n, world=None, rank=None):
+        G = self.world if world is None else world
+        g = self.rank if rank is None else rank
+        k1 = (log_n + 1) // 2
+        k2 = log_n - k1
+        N1, N2 = 1 << k1, 1 << k2
+        if N1 % G or N2 % G:
+            raise ValueError("world size must divide both N1 and N2")
+        R1, W = N1 // G, N2 // G
+        assert x_local.shape == (R1 * N2, 4)
+        # rows -> columns
+        send = x_local.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()
+        M = self.exchange(send).reshape(N1, W, 4)
+        self.ops.columns(M, g * W)
+        # columns -> rows
+        recv = self.exchange(M.view(G, R1, W, 4))
+        T = recv.permute(1, 0, 2, 3).contiguous().view(R1, N2, 4)
+        self.ops.rows(T)
+        # (t, b) -> natural index b*N1 + t
+        send = T.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()
+        recv = self.exchange(send)
+        return recv.permute(2, 0, 1, 3).contiguous().view(W * N1, 4)
+
+
+class GpuNttOps:
+    """Local halves of DistributedNTT on this rank's GPU (tensors on the context's device; the
+    context must share the torch stream: ctx.set_stream(torch.cuda.current_stream().cuda_stream))."""
+
+    def __init__(self, ctx, log_n, w_words, inverse):
+        self.ctx, self.log_n, self.w, self.inverse = ctx, log_n, w_words, inverse
+
+    def columns(self, M, col_base):
+        self.ctx.ntt_columns_device(M.data_ptr(), self.log_n, self.w, self.inverse, M.shape[1], col_base)
+
+    def rows(self, T):
+        self.ctx.ntt_rows_device(T.data_ptr(), self.log_n, self.w, self.inverse, T.shape[0])

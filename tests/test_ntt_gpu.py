@@ -138,3 +138,68 @@ def test_facade_signatures(native):
         fft_ff_interpolation(vals[:12], g, F)              # fft_ff.py:74
     with pytest.raises(AssertionError):
         fft_ff_interpolation(vals, F.root_of_unity(8), F)  # fft_ff.py:78
+
+
+@pytest.mark.parametrize("curve,log_n,world", [("bls12_381", 14, 2), ("bls12_381", 16, 4), ("bn254", 13, 2)])
+def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
+    """kzg_ntt_columns_device / kzg_ntt_rows_device under kzg_snark_amd.sharding.DistributedNTT:
+    `world` Python threads play the ranks (one engine context each, all on cuda:0) and exchange
+    through an in-process all-to-all.  The result must equal the single-GPU transform and, for a
+    slice, the oracle -- forward, inverse and with a w that is not a primitive root."""
+    import threading
+    import torch
+    from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps
+    cv = O.curve(curve)
+    n = 1 << log_n
+    rs = np.random.RandomState(log_n)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(4)
+    x = native.limbs_to_ints(raw)
+    cases = [(cv.root_of_unity(n), False), (cv.root_of_unity(n), True), (0x1234567 % cv.r, False)]
+    for w, inverse in cases:
+        ww = native.int_to_words(w)
+        ref = raw.copy()
+        native.get_context(curve).ntt(ref, log_n, ww, inverse)          # single-GPU result
+        if log_n <= 14:
+            want = O.ifft_ff(x, w, cv.r) if inverse else O.fft_ff(x, w, cv.r)
+            assert native.limbs_to_ints(ref) == want
+        barrier = threading.Barrier(world)
+        mailbox = [None] * world
+        outs = [None] * world
+        errs = []
+
+        def run(rank):
+            try:
+                ctx = native.Context(curve)
+                stream = torch.cuda.Stream(device="cuda:0")
+                ctx.set_stream(stream.cuda_stream)
+
+                def exchange(send):
+                    stream.synchronize()
+                    mailbox[rank] = send
+                    barrier.wait()
+                    recv = torch.stack([mailbox[h][rank] for h in range(world)])
+                    barrier.wait()
+                    return recv
+
+                with torch.cuda.stream(stream):
+                    lo, hi = rank * n // world, (rank + 1) * n // world
+                    xl = torch.from_numpy(raw[lo:hi].view(np.int64)).to("cuda:0")
+                    d = DistributedNTT(GpuNttOps(ctx, log_n, ww, inverse), exchange=exchange)
+                    out = d.transform(xl, log_n, world=world, rank=rank)
+                    stream.synchronize()
+                    ctx.synchronize()
+                    outs[rank] = out.cpu().numpy().view(np.uint64)
+                ctx.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+                barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        got = np.concatenate(outs)
+        assert np.array_equal(got, ref), (w == cases[2][0], inverse)

@@ -613,6 +613,7 @@ struct MsmWork {
   MsmSlot slot[NSLOT];
   hipStream_t stream_p = nullptr, stream_a = nullptr, stream_b = nullptr;
   int next = 0;
+  int prev = -1;               // slot of the previously enqueued polynomial
 };
 
 static MsmWork* get_work(Ctx* c) {
@@ -707,6 +708,16 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, (size_t)16));
   DevBuf& tmp = w->sort_tmp[slot_idx];
   if ((rc = ensure_buf(c, tmp, tmp_bytes))) return rc;
+
+  // Schedule  A(p) | prep(p+1) || reduce(p) | A(p+1):  the accumulate kernel keeps the machine to
+  // itself (sharing it slows both sides: prep of the next polynomial trickles at 1/6 speed), and
+  // the memory-bound prep overlaps the latency-bound reduce.  KZG_MSM_FREE=1 drops the two waits.
+  static const bool free_run = [] { const char* e = getenv("KZG_MSM_FREE"); return e && atoi(e) == 1; }();
+  if (!free_run && w->prev >= 0 && w->prev != slot_idx) {
+    KZG_HIP(c, hipStreamWaitEvent(sp, w->slot[w->prev].ev_a, 0));   // prep(p+1) after accumulate(p)
+    KZG_HIP(c, hipStreamWaitEvent(sa, w->slot[w->prev].ev_b, 0));   // accumulate(p+1) after reduce(p)
+  }
+  w->prev = slot_idx;
 
   // ---- stage P: prep
   KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));

@@ -362,9 +362,9 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* parti
 // the empty digit), in two steps with every lane busy:
 //   step 1: a lane adds RC_CH entries of one column (blockIdx.y = 0) or one row (= 1) serially;
 //           consecutive lanes touch consecutive buckets.  colpart[chunk][lo], rowpart[hi][chunk].
-//   step 2: RC_L2 lanes fold the partials of one column / row (serial + 2 shuffle levels).
-constexpr uint32_t RC_CH = 32;
-constexpr uint32_t RC_L2 = 4;
+//   step 2: RC_L2 lanes fold the partials of one column / row (serial + log2(RC_L2) shuffle levels).
+constexpr uint32_t RC_CH = 8;      // serial depth of step 1 (latency: the stage is a chain of point additions)
+constexpr uint32_t RC_L2 = 16;
 
 template <class C, int WB>
 __global__ __launch_bounds__(128) void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
@@ -416,27 +416,32 @@ __global__ __launch_bounds__(128) void msm_rc2_kernel(const uint32_t* colpart, c
 
 // bit-plane sums of the row-sum and column-sum vectors: block b < HI: T = sum of rowsum[i]
 // with bit b of i set; block HI + b: same over colsum; last block: the top bucket (v = 2^(WB-1)).
+// Two waves per block: short serial part, 6 shuffle levels, one LDS hop.
 template <class C, int WB>
-__global__ __launch_bounds__(64) void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
-                                                        const uint32_t* buckets, uint32_t* out) {
-  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
-  const uint32_t blk = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(128) void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
+                                                         const uint32_t* buckets, uint32_t* out) {
+  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI, N = C::Fp::N;
+  __shared__ uint32_t xch[4 * N];
+  const uint32_t blk = blockIdx.x, tid = threadIdx.x;
   XYZZ<C> acc = Ec<C>::infinity();
   if (blk < (uint32_t)(HI + LO)) {
     const bool cols = blk >= (uint32_t)HI;
     const uint32_t b = cols ? blk - HI : blk;
     const uint32_t members = (cols ? (1u << LO) : (1u << HI)) >> 1;
     const uint32_t* src = cols ? colsum : rowsum;
-    for (uint32_t q = lane; q < members; q += 64) {
+    for (uint32_t q = tid; q < members; q += blockDim.x) {
       const uint32_t i = ((q >> b) << (b + 1)) | (1u << b) | (q & ((1u << b) - 1));   // q-th index with bit b set
       acc = Ec<C>::add(acc, load_xyzz<C>(src, i));
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+    if (tid == 64) store_xyzz<C>(xch, 0, acc);
+    __syncthreads();
+    if (tid == 0) acc = Ec<C>::add(acc, load_xyzz<C>(xch, 0));
   } else {
     acc = load_xyzz<C>(buckets, Win<WB>::NB - 1);
   }
-  if (lane == 0) store_xyzz<C>(out, blk, acc);
+  if (tid == 0) store_xyzz<C>(out, blk, acc);
 }
 
 template <class C>
@@ -709,11 +714,11 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   DevBuf& tmp = w->sort_tmp[slot_idx];
   if ((rc = ensure_buf(c, tmp, tmp_bytes))) return rc;
 
-  // Schedule  A(p) | prep(p+1) || reduce(p) | A(p+1):  the accumulate kernel keeps the machine to
-  // itself (sharing it slows both sides: prep of the next polynomial trickles at 1/6 speed), and
-  // the memory-bound prep overlaps the latency-bound reduce.  KZG_MSM_FREE=1 drops the two waits.
-  static const bool free_run = [] { const char* e = getenv("KZG_MSM_FREE"); return e && atoi(e) == 1; }();
-  if (!free_run && w->prev >= 0 && w->prev != slot_idx) {
+  // Optional schedule  A(p) | prep(p+1) || reduce(p) | A(p+1)  (KZG_MSM_SERIAL=1): keeps the
+  // accumulate kernel alone on the machine.  Measured slower (287 vs 309 commits/s) than letting
+  // the three stages run freely, so it is off by default.
+  static const bool serial = [] { const char* e = getenv("KZG_MSM_SERIAL"); return e && atoi(e) == 1; }();
+  if (serial && w->prev >= 0 && w->prev != slot_idx) {
     KZG_HIP(c, hipStreamWaitEvent(sp, w->slot[w->prev].ev_a, 0));   // prep(p+1) after accumulate(p)
     KZG_HIP(c, hipStreamWaitEvent(sa, w->slot[w->prev].ev_b, 0));   // accumulate(p+1) after reduce(p)
   }
@@ -773,7 +778,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
     hipLaunchKernelGGL((msm_rc2_kernel<C, WB>), dim3((((1u << W::LO) + (1u << W::HI)) * RC_L2 + 127) / 128),
                        dim3(128), 0, sb, static_cast<uint32_t*>(sl.colpart.p), static_cast<uint32_t*>(sl.rowpart.p),
                        static_cast<uint32_t*>(sl.colsum.p), static_cast<uint32_t*>(sl.rowsum.p));
-    hipLaunchKernelGGL((msm_planes_kernel<C, WB>), dim3(W::NPART), dim3(64), 0, sb,
+    hipLaunchKernelGGL((msm_planes_kernel<C, WB>), dim3(W::NPART), dim3(128), 0, sb,
                        static_cast<uint32_t*>(sl.rowsum.p), static_cast<uint32_t*>(sl.colsum.p),
                        static_cast<uint32_t*>(sl.buckets.p), static_cast<uint32_t*>(sl.tb.p));
   }

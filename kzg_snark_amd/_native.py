@@ -74,6 +74,27 @@ _lib = None
 MISSING = []
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If this
+    library were loaded first it would bind the system runtime and a later `import torch` would
+    start a SECOND HIP runtime in the process (torch then reports "No HIP GPUs are available", and
+    stream handles could not be shared).  Loading torch's copy first -- by path, without importing
+    torch -- makes both sides resolve to one runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the shared library (no GPU needed for loading; needed for contexts)."""
     global _lib
@@ -81,6 +102,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NativeUnavailable(
                 f"{LIB_PATH} not built: run `python -m kzg_snark_amd.build` (no CPU fallback exists)")
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name, None)

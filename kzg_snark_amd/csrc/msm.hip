@@ -616,7 +616,7 @@ struct MsmSlot {
 struct MsmWork {
   DevBuf sort_tmp[NSLOT];
   MsmSlot slot[NSLOT];
-  hipStream_t stream_p = nullptr, stream_a = nullptr, stream_b = nullptr;
+  hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_a = nullptr, stream_b = nullptr;
   int next = 0;
   int prev = -1;               // slot of the previously enqueued polynomial
 };
@@ -638,7 +638,7 @@ void msm_free_work(Ctx* c) {
     for (hipEvent_t e : {sl.ev_in, sl.ev_p, sl.ev_a, sl.ev_b})
       if (e) hipEventDestroy(e);
   }
-  for (hipStream_t st : {w->stream_p, w->stream_a, w->stream_b})
+  for (hipStream_t st : {w->stream_p, w->stream_p2, w->stream_a, w->stream_b})
     if (st) hipStreamDestroy(st);
   delete w;
   c->msm_work = nullptr;
@@ -686,6 +686,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
     const bool use_prio = !(e && atoi(e) == 0) && lo_prio != hi_prio;
     KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_a, hipStreamNonBlocking, use_prio ? lo_prio : 0));
     KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_p, hipStreamNonBlocking, use_prio ? hi_prio : 0));
+    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_p2, hipStreamNonBlocking, use_prio ? hi_prio : 0));
     KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_b, hipStreamNonBlocking, use_prio ? hi_prio : 0));
   }
   sl.win_bits = WB;
@@ -703,7 +704,10 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
   // KZG_MSM_STREAMS=2: prep shares the accumulate stream (only the reduce stage overlaps)
   static const bool two_streams = [] { const char* e = getenv("KZG_MSM_STREAMS"); return e && atoi(e) == 2; }();
-  hipStream_t sa = w->stream_a, sb = w->stream_b, sp = two_streams ? sa : w->stream_p;
+  // KZG_MSM_PREP_STREAMS=2: consecutive polynomials prepare on alternating streams
+  static const bool two_prep = [] { const char* e = getenv("KZG_MSM_PREP_STREAMS"); return e && atoi(e) == 2; }();
+  hipStream_t sa = w->stream_a, sb = w->stream_b;
+  hipStream_t sp = two_streams ? sa : ((two_prep && (slot_idx & 1)) ? w->stream_p2 : w->stream_p);
 
   constexpr unsigned SORT_BITS = WB <= 16 ? 16 : WB;
   size_t t1 = 0, t2 = 0, t3 = 0;

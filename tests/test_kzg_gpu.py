@@ -185,6 +185,39 @@ def test_commit_2_18_bn254_trapdoor(native, kzgs):
     assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
 
 
+def test_ntt_and_commit_2_22(native, kzgs):
+    """Beyond the benchmark size: 2^22 evaluations -> INTT -> commit against a 2^22-point key
+    (device-resident pipeline), trapdoor identity on the result; NTT checked by its round trip
+    and by X[0] = sum(x)."""
+    import torch
+    cv = O.BLS12_381
+    kzg = kzgs["bls12_381"]
+    ctx = native.get_context("bls12_381")
+    log_n = 22
+    n = 1 << log_n
+    tau = 0x77aa55cc33 % cv.r
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    rs = np.random.RandomState(22)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(3)
+    w = cv.root_of_unity(n)
+    ww = native.int_to_words(w)
+    d = torch.from_numpy(raw.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    ctx.ntt_device(d.data_ptr(), log_n, ww, True, 1)                 # evaluations -> coefficients
+    ctx.synchronize()
+    coeff_raw = d.cpu().numpy().view(np.uint64)
+    coeffs = native.limbs_to_ints(coeff_raw)
+    x = native.limbs_to_ints(raw)
+    assert coeffs[0] == sum(x) * pow(n, -1, cv.r) % cv.r               # c_0 = mean of the evaluations
+    xy, inf = ctx.commit_device(ck.srs, d.data_ptr(), [n], n)
+    got = native.limbs_to_ints(xy.reshape(2, 6))
+    assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+    ctx.ntt_device(d.data_ptr(), log_n, ww, False, 1)                # back to evaluations
+    ctx.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64), raw)
+
+
 def test_commit_full_size_2_20_trapdoor(native, kzgs):
     """BASELINE config 3: degree-2^20 commit on BLS12-381 against a 2^20-point SRS.
     The oracle's naive commit is hours at this size; parity is the trapdoor

@@ -104,6 +104,33 @@ struct Ec {
     return r;
   }
 
+  // madd for an accumulator known to be finite; `finite` is cleared when the sum is infinity.
+  // The hot loop of the MSM: tracks infinity in a flag instead of testing ZZ every time.
+  static KZG_HD P madd_finite(const P& a, const E& x2, const E& y2, bool& finite) {
+    const E U2 = Fd::mul(x2, a.zz);
+    const E S2 = Fd::mul(y2, a.zzz);
+    const E Pp = Fd::sub(U2, a.x);
+    const E R = Fd::sub(S2, a.y);
+    if (Fd::is_zero_weak(Pp)) {
+      if (Fd::is_zero_weak(R)) {
+        const P d = dbl_affine(x2, y2);
+        finite = !is_inf(d);
+        return d;
+      }
+      finite = false;
+      return infinity();
+    }
+    const E PP = Fd::sqr(Pp);
+    const E PPP = Fd::mul(Pp, PP);
+    const E Q = Fd::mul(a.x, PP);
+    P r;
+    r.x = Fd::sub(Fd::sub(Fd::sqr(R), PPP), Fd::dbl(Q));
+    r.y = Fd::mul2(R, Fd::sub(Q, r.x), Fd::neg_weak(a.y), PPP);
+    r.zz = Fd::mul(a.zz, PP);
+    r.zzz = Fd::mul(a.zzz, PPP);
+    return r;
+  }
+
   static KZG_HD P add(const P& a, const P& b) {
     if (is_inf(a)) return b;
     if (is_inf(b)) return a;

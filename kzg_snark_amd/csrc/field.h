@@ -342,6 +342,38 @@ struct Field {
     return acc == 0;
   }
   static KZG_HD bool eq(const E& a, const E& b) { return is_zero(sub(a, b)); }
+  // zero test without the reduction: a weak-normal value is 0 mod p iff it is the integer 0 or
+  // the integer p, and normalised limbs represent an integer uniquely
+  static KZG_HD bool is_zero_weak(const E& a) {
+    uint32_t z = 0, q = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { z |= a.l[j]; q |= a.l[j] ^ F::P[j]; }
+    return z == 0 || q == 0;
+  }
+  // 2p - a for weak-normal a: normalised limbs, value in (0, 2p] (fine as a mul operand)
+  static KZG_HD E neg_weak(const E& a) {
+    E r;
+    int32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int32_t t = (int32_t)F::P2[j] - (int32_t)a.l[j] + c;
+      if (j < N - 1) { c = t >> L; r.l[j] = (uint32_t)t & MASK; } else { r.l[j] = (uint32_t)t; }
+    }
+    return r;
+  }
+  // flag ? p - a : a  for CANONICAL a (table coordinates): result weak-normal in [0, p]
+  static KZG_HD E cneg_canonical(const E& a, bool flag) {
+    E r;
+    int32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int32_t t = (int32_t)F::P[j] - (int32_t)a.l[j] + c;
+      uint32_t v;
+      if (j < N - 1) { c = t >> L; v = (uint32_t)t & MASK; } else { v = (uint32_t)t; }
+      r.l[j] = flag ? v : a.l[j];
+    }
+    return r;
+  }
 
   static KZG_HD E to_mont(const E& a) { return mul(a, r2()); }
   static KZG_HD E from_mont(const E& a) { return reduce(mul(a, raw_one())); }

@@ -330,14 +330,20 @@ __global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* rec
   const uint32_t e0 = b0 + (uint32_t)(((uint64_t)s * len) / ns);
   const uint32_t e1 = b0 + (uint32_t)(((uint64_t)(s + 1) * len) / ns);
   XYZZ<C> acc = Ec<C>::infinity();
+  bool finite = false;                       // accumulator is the point at infinity
   for (uint32_t e = e0; e < e1; ++e) {
     const uint32_t v = vals[e];
     Fe<F> x, y;
-    load_rec<C>(recs, v & 0x7fffffffu, x, y);
-    const Fe<F> yn = Fd::neg(y);
-    y = Fd::select(v >> 31, yn, y);
-    acc = Ec<C>::madd(acc, x, y);
+    load_rec<C>(recs, v & 0x7fffffffu, x, y);           // table coordinates are canonical
+    y = Fd::cneg_canonical(y, v >> 31);
+    if (!finite) {
+      acc.x = x; acc.y = y; acc.zz = Fd::one(); acc.zzz = Fd::one();
+      finite = true;
+    } else {
+      acc = Ec<C>::madd_finite(acc, x, y, finite);
+    }
   }
+  if (!finite) acc = Ec<C>::infinity();
   store_xyzz<C>(partials, t, acc);
 }
 

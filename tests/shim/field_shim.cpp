@@ -26,6 +26,11 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     case 7: R = Fd::sqr(A); break;
     case 8: R = Fd::mul2(A, B, Fd::add(A, B), Fd::sub(B, A)); break;   // a*b + (a+b)*(b-a)
     case 9: R = Fd::sqr(Fd::sub(A, B)); break;
+    case 10: R = Fd::neg_weak(Fd::sub(A, B)); break;                       // -(a - b)
+    case 11: R = Fd::cneg_canonical(Fd::reduce(A), true); break;            // -a
+    case 12: R = Fd::cneg_canonical(Fd::reduce(A), false); break;           // a
+    case 13: R = Fd::is_zero_weak(Fd::sub(A, B)) == Fd::is_zero(Fd::sub(A, B))
+                     ? (Fd::is_zero_weak(Fd::sub(A, B)) ? Fd::one() : Fd::zero()) : Fd::add(Fd::one(), Fd::one()); break;
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);
@@ -69,6 +74,21 @@ static int ec_op(int which, const uint32_t* p1, int inf1, const uint32_t* p2, in
     case 0: R = B.inf ? E::from_affine(A) : E::madd(E::from_affine(A), B.x, B.y); break;
     case 1: R = E::add(E::from_affine(A), E::from_affine(B)); break;
     case 2: R = E::dbl(E::from_affine(A)); break;
+    case 4: {  // the MSM inner loop form: flag-tracked accumulator, A + B - B + B + A (passes through infinity? no: through A)
+      bool fin = true;
+      XYZZ<C> t = E::from_affine(A);
+      auto step = [&](const Affine<C>& q, bool negate) {
+        const auto y = Fd::cneg_canonical(Fd::reduce(q.y), negate);
+        const auto x = Fd::reduce(q.x);
+        if (!fin) { t.x = x; t.y = y; t.zz = Fd::one(); t.zzz = Fd::one(); fin = true; }
+        else t = E::madd_finite(t, x, y, fin);
+      };
+      step(B, false); step(B, true); step(A, true);      // A + B - B - A = O
+      if (fin) return -2;
+      step(B, false); step(B, false); step(A, false);    // O + B + B (doubling) + A
+      R = fin ? t : E::infinity();
+      break;
+    }
     case 3: {  // ((A + B) + B) + A with a projective accumulator
       XYZZ<C> t = E::madd(E::from_affine(A), B.x, B.y);
       t = E::madd(t, B.x, B.y);

@@ -38,7 +38,8 @@ def test_field_ops(shim, fid, p, nw):
            (4, lambda a, b: (-a) % p), (5, lambda a, b: 2 * a % p),
            (6, lambda a, b: ((((a + b) * (a - b) + a) * b) + b) % p),
            (7, lambda a, b: a * a % p), (8, lambda a, b: (a * b + (a + b) * (b - a)) % p),
-           (9, lambda a, b: (a - b) * (a - b) % p)]
+           (9, lambda a, b: (a - b) * (a - b) % p), (10, lambda a, b: (b - a) % p), (11, lambda a, b: (-a) % p),
+           (12, lambda a, b: a % p), (13, lambda a, b: 1 if (a - b) % p == 0 else 0)]
     for _ in range(1500):
         a = rng.choice([0, 1, 2, p - 1, p - 2, rng.randrange(p), rng.randrange(p), 1 << (p.bit_length() - 1)])
         b = rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)])
@@ -95,5 +96,7 @@ def test_ec_ops(shim, cid, cv, nw):
             check(op, inf, inf, inf)
     check(2, a, a, O.double(a, cv))       # dbl
     check(2, inf, inf, inf)
+    # the MSM inner loop (flag-tracked infinity, conditional negation): a + b - b - a = O, then + b + b + a
+    check(4, a, b, O.add(O.double(b, cv), a, cv))
     # a non-trivial Z on the accumulator side: ((a + b) + b) + a
     check(3, a, b, O.add(O.add(O.add(a, b, cv), b, cv), a, cv))

@@ -21,9 +21,15 @@ class FieldElement:
             return o.v
         return int(o) % self.F.p
 
-    def __add__(self, o): return FieldElement((self.v + self._c(o)) % self.F.p, self.F)
+    def __add__(self, o):
+        if isinstance(o, Polynomial):
+            return NotImplemented            # Polynomial.__radd__ takes over
+        return FieldElement((self.v + self._c(o)) % self.F.p, self.F)
     __radd__ = __add__
-    def __sub__(self, o): return FieldElement((self.v - self._c(o)) % self.F.p, self.F)
+    def __sub__(self, o):
+        if isinstance(o, Polynomial):
+            return NotImplemented            # Polynomial.__rsub__
+        return FieldElement((self.v - self._c(o)) % self.F.p, self.F)
     def __rsub__(self, o): return FieldElement((self._c(o) - self.v) % self.F.p, self.F)
     def __mul__(self, o):
         if isinstance(o, Polynomial):

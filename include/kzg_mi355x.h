@@ -156,6 +156,26 @@ int kzg_open_shard_begin(kzg_ctx* ctx, const void* d_polys, const size_t* lens, 
 int kzg_open_shard_finish(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t z[4], const uint64_t carry[4],
                           int first_rank, uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out);
 
+/* ---- device vector / polynomial primitives over Fr ------------------------------------------------
+ * What the reference's callers do with Sage's dense polynomials between the transforms and the
+ * commitments (plonk/prover.py:243-316: accumulator ratios, products, division by Z_H on a coset),
+ * as passes over device-resident vectors of canonical 32-byte elements.  All enqueue on the context's
+ * stream; out may alias an input for the element-wise ones.
+ *   vec_op          out[i] = a[i] (+ | - | *) b[i]            op: 0 add, 1 sub, 2 mul
+ *   vec_lincomb     out[i] = sum_j scalars[j] * p_j[i]         (p_j of lens[j] < n read as zero-padded)
+ *   vec_mul_powers  out[i] = a[i] * c0 * s^i                   (coset shift of a coefficient vector)
+ *   vec_inverse     out[i] = a[i]^-1, 0 -> 0
+ *   vec_prefix_product  out[i] = prod_(j<i) a[j]               (exclusive; out[0] = 1)
+ *   poly_eval       out = sum_i a[i] z^i                       (synchronises) */
+int kzg_fr_vec_op(kzg_ctx* ctx, int op, size_t n, const void* d_a, const void* d_b, void* d_out);
+int kzg_fr_vec_lincomb(kzg_ctx* ctx, size_t n, size_t k, const void* const* d_ptrs, const size_t* lens,
+                       const uint64_t* scalars, void* d_out);
+int kzg_fr_vec_mul_powers(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t s[4], const uint64_t c0[4],
+                          void* d_out);
+int kzg_fr_vec_inverse(kzg_ctx* ctx, size_t n, const void* d_a, void* d_out);
+int kzg_fr_vec_prefix_product(kzg_ctx* ctx, size_t n, const void* d_a, void* d_out);
+int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4], uint64_t out[4]);
+
 /* ---- measurement hooks (bench.py) -----------------------------------------------------------
  * When enabled, the library brackets its kernels with HIP events on the context's stream.
  * Span names: "ntt_pass", "msm_digits", "msm_sort", "msm_bounds", "msm_accumulate",

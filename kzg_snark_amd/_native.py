@@ -52,6 +52,12 @@ SIGNATURES = {
     "kzg_open": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "kzg_open_shard_begin": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp]),
     "kzg_open_shard_finish": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    "kzg_fr_vec_op": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_size_t, _vp, _vp, _vp]),
+    "kzg_fr_vec_lincomb": (ctypes.c_int, [_vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp]),
+    "kzg_fr_vec_mul_powers": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _vp, _vp]),
+    "kzg_fr_vec_inverse": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp]),
+    "kzg_fr_vec_prefix_product": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp]),
+    "kzg_fr_poly_eval": (ctypes.c_int, [_vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "kzg_prof_enable": (ctypes.c_int, [_vp, ctypes.c_int]),
     "kzg_prof_reset": (ctypes.c_int, [_vp]),
     "kzg_prof_read": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -254,6 +260,34 @@ class Context:
                        _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf), _as_vp(ev)))
         return out_xy, out_inf, ev
 
+
+    # ---- device vector / polynomial primitives (device pointers, canonical elements)
+    def vec_op(self, op, n, d_a, d_b, d_out):
+        self._check(lib().kzg_fr_vec_op(self._h, {"add": 0, "sub": 1, "mul": 2}[op], n, _as_vp(d_a), _as_vp(d_b),
+                                        _as_vp(d_out)))
+
+    def vec_lincomb(self, n, d_ptrs, lens, scalars, d_out):
+        k = len(d_ptrs)
+        ptrs = (ctypes.c_void_p * max(k, 1))(*[int(p) for p in d_ptrs])
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        sc = np.ascontiguousarray(np.concatenate([int_to_words(int(s)) for s in scalars]) if k else np.zeros(4, np.uint64))
+        self._check(lib().kzg_fr_vec_lincomb(self._h, n, k, ctypes.cast(ptrs, ctypes.c_void_p), _as_vp(lens_a),
+                                             _as_vp(sc), _as_vp(d_out)))
+
+    def vec_mul_powers(self, n, d_a, s, c0, d_out):
+        self._check(lib().kzg_fr_vec_mul_powers(self._h, n, _as_vp(d_a), _as_vp(int_to_words(int(s))),
+                                                _as_vp(int_to_words(int(c0))), _as_vp(d_out)))
+
+    def vec_inverse(self, n, d_a, d_out):
+        self._check(lib().kzg_fr_vec_inverse(self._h, n, _as_vp(d_a), _as_vp(d_out)))
+
+    def vec_prefix_product(self, n, d_a, d_out):
+        self._check(lib().kzg_fr_vec_prefix_product(self._h, n, _as_vp(d_a), _as_vp(d_out)))
+
+    def poly_eval(self, n, d_a, z):
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(lib().kzg_fr_poly_eval(self._h, n, _as_vp(d_a), _as_vp(int_to_words(int(z))), _as_vp(out)))
+        return int.from_bytes(out.tobytes(), "little")
 
     # ---- sharded open (device pointers)
     def open_shard_begin(self, d_polys, lens, stride, z_words, xi_words):

@@ -17,6 +17,7 @@ SOURCES = ["api.hip", "ntt.hip", "msm.hip", "poly.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+FLAGS += os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _deps():

@@ -332,6 +332,53 @@ int kzg_open_shard_finish(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t z[4],
   return commit_device(c, srs->s, d_vec, &len, 1, len ? len : 1, out_xy, out_inf);
 }
 
+#define KZG_VEC_ENTER()                          \
+  if (!ctx) return KZG_ERR_ARG;                  \
+  Ctx* c = &ctx->c;                              \
+  KZG_HIP(c, hipSetDevice(c->device));
+
+int kzg_fr_vec_op(kzg_ctx* ctx, int op, size_t n, const void* d_a, const void* d_b, void* d_out) {
+  KZG_VEC_ENTER();
+  if (op < 0 || op > 2 || (n && (!d_a || !d_b || !d_out))) return KZG_ERR_ARG;
+  return fr_vec_binary(c, op, n, static_cast<const uint32_t*>(d_a), static_cast<const uint32_t*>(d_b),
+                       static_cast<uint32_t*>(d_out));
+}
+
+int kzg_fr_vec_lincomb(kzg_ctx* ctx, size_t n, size_t k, const void* const* d_ptrs, const size_t* lens,
+                       const uint64_t* scalars, void* d_out) {
+  KZG_VEC_ENTER();
+  if (k && (!d_ptrs || !lens || !scalars)) return KZG_ERR_ARG;
+  if (n && !d_out) return KZG_ERR_ARG;
+  return fr_vec_lincomb(c, n, k, reinterpret_cast<const uint32_t* const*>(d_ptrs), lens,
+                        reinterpret_cast<const uint32_t*>(scalars), static_cast<uint32_t*>(d_out));
+}
+
+int kzg_fr_vec_mul_powers(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t s[4], const uint64_t c0[4],
+                          void* d_out) {
+  KZG_VEC_ENTER();
+  if (!s || !c0 || (n && (!d_a || !d_out))) return KZG_ERR_ARG;
+  return fr_vec_mul_powers(c, n, static_cast<const uint32_t*>(d_a), reinterpret_cast<const uint32_t*>(s),
+                           reinterpret_cast<const uint32_t*>(c0), static_cast<uint32_t*>(d_out));
+}
+
+int kzg_fr_vec_inverse(kzg_ctx* ctx, size_t n, const void* d_a, void* d_out) {
+  KZG_VEC_ENTER();
+  if (n && (!d_a || !d_out)) return KZG_ERR_ARG;
+  return fr_vec_inverse(c, n, static_cast<const uint32_t*>(d_a), static_cast<uint32_t*>(d_out));
+}
+
+int kzg_fr_vec_prefix_product(kzg_ctx* ctx, size_t n, const void* d_a, void* d_out) {
+  KZG_VEC_ENTER();
+  if (n && (!d_a || !d_out)) return KZG_ERR_ARG;
+  return fr_vec_prefix_product(c, n, static_cast<const uint32_t*>(d_a), static_cast<uint32_t*>(d_out));
+}
+
+int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4], uint64_t out[4]) {
+  KZG_VEC_ENTER();
+  if (!z || !out || (n && !d_a)) return KZG_ERR_ARG;
+  return fr_poly_eval(c, n, static_cast<const uint32_t*>(d_a), reinterpret_cast<const uint32_t*>(z), out);
+}
+
 int kzg_prof_enable(kzg_ctx* ctx, int on) {
   if (!ctx) return KZG_ERR_ARG;
   ctx->c.prof_on = on != 0;

@@ -92,4 +92,13 @@ int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t*
                        uint64_t count, uint64_t col_base);
 void ntt_free_domains(Ctx* c);
 
+// poly.hip: device vector / polynomial primitives over Fr
+int fr_vec_binary(Ctx* c, int op, size_t n, const uint32_t* a, const uint32_t* b, uint32_t* out);
+int fr_vec_lincomb(Ctx* c, size_t n, size_t k, const uint32_t* const* ptrs, const size_t* lens, const uint32_t* scalars,
+                   uint32_t* out);
+int fr_vec_mul_powers(Ctx* c, size_t n, const uint32_t* a, const uint32_t* s, const uint32_t* cc, uint32_t* out);
+int fr_vec_inverse(Ctx* c, size_t n, const uint32_t* a, uint32_t* out);
+int fr_vec_prefix_product(Ctx* c, size_t n, const uint32_t* a, uint32_t* out);
+int fr_poly_eval(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z, uint64_t* out);
+
 }  // namespace kzg

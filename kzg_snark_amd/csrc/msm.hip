@@ -306,8 +306,13 @@ __global__ void msm_ns_kernel(const uint32_t* bstart, const uint32_t* order, uin
   ns[r] = (bstart[k + 1] - bstart[k] + Win<WB>::SEG - 1) / Win<WB>::SEG;
 }
 
+#ifdef KZG_ACC_TWO_WAVES
+#define KZG_ACC_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
+#else
+#define KZG_ACC_ATTR
+#endif
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
+__global__ __launch_bounds__(128) KZG_ACC_ATTR void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
                                                              const uint32_t* bstart, const uint32_t* order,
                                                              const uint32_t* slice_off, uint32_t* partials) {
   using F = typename C::Fp;

@@ -341,3 +341,297 @@ int device_any_nonzero(Ctx* c, const uint32_t* d_words, size_t from, size_t to, 
 }
 
 }  // namespace kzg
+
+// =====================================================================================
+// Device polynomial / vector primitives over Fr (include/kzg_mi355x.h "kzg_fr_*").  What the
+// reference's callers get from Sage's dense polynomial arithmetic (plonk/prover.py:243-316:
+// accumulator ratios, products, division by Z_H on a coset) expressed as data-parallel passes
+// over device-resident coefficient / evaluation vectors.
+// =====================================================================================
+namespace kzg {
+namespace {
+
+enum : int { VEC_ADD = 0, VEC_SUB = 1, VEC_MUL = 2 };
+
+template <class F>
+__global__ void vec_binary_kernel(int op, size_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  using Fd = Field<F>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fe<F> x = load_words<F>(a + i * 8), y = load_words<F>(b + i * 8);
+  Fe<F> r;
+  if (op == VEC_ADD) r = Fd::add(x, y);
+  else if (op == VEC_SUB) r = Fd::sub(x, y);
+  else r = Fd::mul(Fd::to_mont(x), y);          // (xR)*y/R = x*y
+  store_words<F>(out + i * 8, r);
+}
+
+struct ScalarLincombArgs {
+  const uint32_t* ptr[MAXK];
+  uint32_t len[MAXK];
+  uint32_t k;
+};
+// out[i] = sum_j s_j * p_j[i]  (s_j in Montgomery form; p_j shorter than n count as zero-padded)
+template <class F>
+__global__ void vec_lincomb_kernel(ScalarLincombArgs a, const uint32_t* scal, uint32_t* out, uint32_t n) {
+  using Fd = Field<F>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Fe<F> acc = Fd::zero();
+  for (uint32_t j = 0; j < a.k; ++j)
+    if (t < a.len[j]) acc = Fd::add(acc, Fd::mul(load_words<F>(a.ptr[j] + (size_t)t * 8), load_limbs<F>(scal + j * F::N)));
+  store_words<F>(out + (size_t)t * 8, acc);
+}
+
+// out[i] = a[i] * c * s^i : thread handles LC consecutive i (one pow per chunk, then a running product)
+template <class F>
+__global__ void vec_mul_powers_kernel(size_t n, const uint32_t* a, const uint32_t* s_c, uint32_t* out) {
+  using Fd = Field<F>;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i0 = t * LC;
+  if (i0 >= n) return;
+  const Fe<F> s = load_limbs<F>(s_c);
+  Fe<F> b = s, p = load_limbs<F>(s_c + F::N);          // p = c (Montgomery)
+  for (size_t bits = i0; bits; bits >>= 1) {            // p = c * s^i0
+    if (bits & 1u) p = Fd::mul(p, b);
+    b = Fd::mul(b, b);
+  }
+  const size_t i1 = i0 + LC < n ? i0 + LC : n;
+  for (size_t i = i0; i < i1; ++i) {
+    store_words<F>(out + i * 8, Fd::mul(load_words<F>(a + i * 8), p));
+    p = Fd::mul(p, s);
+  }
+}
+
+// out[i] = a[i]^-1 (0 -> 0), Fermat: one exponentiation per element, fully parallel
+template <class F>
+__global__ void vec_inverse_kernel(size_t n, const uint32_t* a, uint32_t* out) {
+  using Fd = Field<F>;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fe<F> x = Fd::to_mont(load_words<F>(a + i * 8));
+  store_words<F>(out + i * 8, Fd::from_mont(Fd::inv(x)));
+}
+
+// Exclusive prefix product out[i] = prod_{j<i} a[j], three steps with chunks of LC:
+//   1 chunk products (and level-up while more than LC chunks remain), 2 serial scan of the top,
+//   3 refill.  Values travel in Montgomery form between the steps.
+template <class F, bool WORDS_IN>
+__global__ void chunk_prod_kernel(const uint32_t* in, uint32_t m, uint32_t* prod) {
+  using Fd = Field<F>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j0 = t * LC;
+  if (j0 >= m) return;
+  const uint32_t j1 = min(j0 + LC, m);
+  Fe<F> acc = Fd::one();
+  for (uint32_t j = j0; j < j1; ++j)
+    acc = Fd::mul(acc, WORDS_IN ? Fd::to_mont(load_words<F>(in + (size_t)j * 8)) : load_limbs<F>(in + (size_t)j * F::N));
+  store_limbs<F>(prod + (size_t)t * F::N, acc);
+}
+template <class F>
+__global__ void top_prefix_kernel(const uint32_t* in, uint32_t m, uint32_t* pre) {   // pre[j] = prod_{i<j} in[i]
+  using Fd = Field<F>;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Fe<F> acc = Fd::one();
+  for (uint32_t j = 0; j < m; ++j) {
+    store_limbs<F>(pre + (size_t)j * F::N, acc);
+    acc = Fd::mul(acc, load_limbs<F>(in + (size_t)j * F::N));
+  }
+}
+// pre_out[j] for j in chunk t = pre_up[t] * prod_{chunk start <= i < j} in[i]
+template <class F, bool FINAL>
+__global__ void chunk_prefix_fill_kernel(const uint32_t* in, uint32_t m, const uint32_t* pre_up, uint32_t* pre_out) {
+  using Fd = Field<F>;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j0 = t * LC;
+  if (j0 >= m) return;
+  const uint32_t j1 = min(j0 + LC, m);
+  Fe<F> acc = load_limbs<F>(pre_up + (size_t)t * F::N);
+  for (uint32_t j = j0; j < j1; ++j) {
+    if (FINAL) {
+      store_words<F>(pre_out + (size_t)j * 8, Fd::from_mont(acc));
+      acc = Fd::mul(acc, Fd::to_mont(load_words<F>(in + (size_t)j * 8)));
+    } else {
+      store_limbs<F>(pre_out + (size_t)j * F::N, acc);
+      acc = Fd::mul(acc, load_limbs<F>(in + (size_t)j * F::N));
+    }
+  }
+}
+
+template <class F>
+int vec_binary_t(Ctx* c, int op, size_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  if (n == 0) return KZG_OK;
+  hipLaunchKernelGGL(vec_binary_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, op, n, a, b, out);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
+int vec_lincomb_t(Ctx* c, size_t n, size_t k, const uint32_t* const* ptrs, const size_t* lens, const uint32_t* scalars,
+                  uint32_t* out) {
+  using Fd = Field<F>;
+  if (k > MAXK) return set_err(c, KZG_ERR_ARG, "kzg_fr_vec_lincomb: more than 64 terms");
+  if (n == 0) return KZG_OK;
+  if (n >= (1ull << 32)) return set_err(c, KZG_ERR_ARG, "vector too long");
+  std::vector<uint32_t> hs(std::max<size_t>(k, 1) * F::N);
+  ScalarLincombArgs la{};
+  la.k = (uint32_t)k;
+  for (size_t j = 0; j < k; ++j) {
+    const Fe<F> s = Fd::to_mont(Fd::from_words(scalars + j * 8));
+    memcpy(&hs[j * F::N], s.l, F::N * 4);
+    la.ptr[j] = ptrs[j];
+    la.len[j] = (uint32_t)std::min(lens[j], n);
+  }
+  int rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[1], (k + 16) * F::N * 4))) return rc;
+  uint32_t* d_sc = static_cast<uint32_t*>(c->poly_tmp[1].p);
+  KZG_HIP(c, hipMemcpyAsync(d_sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  hipLaunchKernelGGL(vec_lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_sc, out,
+                     (uint32_t)n);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
+int vec_mul_powers_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* s_words, const uint32_t* c_words,
+                     uint32_t* out) {
+  using Fd = Field<F>;
+  if (n == 0) return KZG_OK;
+  uint32_t hs[2 * F::N];
+  const Fe<F> s = Fd::to_mont(Fd::from_words(s_words)), cc = Fd::to_mont(Fd::from_words(c_words));
+  memcpy(hs, s.l, F::N * 4);
+  memcpy(hs + F::N, cc.l, F::N * 4);
+  int rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[1], (16 + 2) * F::N * 4))) return rc;
+  uint32_t* d_sc = static_cast<uint32_t*>(c->poly_tmp[1].p);
+  KZG_HIP(c, hipMemcpyAsync(d_sc, hs, sizeof(hs), hipMemcpyHostToDevice, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t chunks = (n + LC - 1) / LC;
+  hipLaunchKernelGGL(vec_mul_powers_kernel<F>, dim3((uint32_t)((chunks + 127) / 128)), dim3(128), 0, c->stream, n, a,
+                     d_sc, out);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
+int vec_inverse_t(Ctx* c, size_t n, const uint32_t* a, uint32_t* out) {
+  if (n == 0) return KZG_OK;
+  hipLaunchKernelGGL(vec_inverse_kernel<F>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, c->stream, n, a, out);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
+int vec_prefix_product_t(Ctx* c, size_t n, const uint32_t* a, uint32_t* out) {
+  if (n == 0) return KZG_OK;
+  if (n >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "vector too long");
+  std::vector<uint32_t> m{(uint32_t)n};
+  while (m.back() > LC) m.push_back((m.back() + LC - 1) / LC);
+  const size_t nl = m.size();
+  size_t total = 0;
+  for (size_t l = 1; l < nl; ++l) total += m[l];
+  int rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[2], (total + 1) * F::N * 4))) return rc;      // chunk products per level
+  if ((rc = ensure_buf(c, c->poly_tmp[3], (total + LC + 1) * F::N * 4))) return rc; // prefixes per level
+  uint32_t* d_p = static_cast<uint32_t*>(c->poly_tmp[2].p);
+  uint32_t* d_q = static_cast<uint32_t*>(c->poly_tmp[3].p);
+  std::vector<uint32_t*> pp(nl, nullptr), qq(nl, nullptr);
+  {
+    uint32_t* x = d_p; uint32_t* y = d_q;
+    for (size_t l = 1; l < nl; ++l) { pp[l] = x; x += (size_t)m[l] * F::N; qq[l] = y; y += (size_t)m[l] * F::N; }
+  }
+  auto grid = [](uint32_t chunks) { return dim3((chunks + 127) / 128); };
+  if (nl == 1) {
+    // a single chunk: its incoming prefix is 1
+    const Fe<F> one = Field<F>::one();
+    KZG_HIP(c, hipMemcpyAsync(d_q, one.l, F::N * 4, hipMemcpyHostToDevice, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL((chunk_prefix_fill_kernel<F, true>), dim3(1), dim3(64), 0, c->stream, a, m[0], d_q, out);
+  } else {
+    hipLaunchKernelGGL((chunk_prod_kernel<F, true>), grid(m[1]), dim3(128), 0, c->stream, a, m[0], pp[1]);
+    for (size_t l = 1; l + 1 < nl; ++l)
+      hipLaunchKernelGGL((chunk_prod_kernel<F, false>), grid(m[l + 1]), dim3(128), 0, c->stream, pp[l], m[l], pp[l + 1]);
+    hipLaunchKernelGGL(top_prefix_kernel<F>, dim3(1), dim3(64), 0, c->stream, pp[nl - 1], m[nl - 1], qq[nl - 1]);
+    for (size_t l = nl - 2; l >= 1; --l)
+      hipLaunchKernelGGL((chunk_prefix_fill_kernel<F, false>), grid(m[l + 1]), dim3(128), 0, c->stream, pp[l], m[l],
+                         qq[l + 1], qq[l]);
+    hipLaunchKernelGGL((chunk_prefix_fill_kernel<F, true>), grid(m[1]), dim3(128), 0, c->stream, a, m[0], qq[1], out);
+  }
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+// p(z) for a coefficient vector: the bottom-up half of the open() scan
+template <class F>
+int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, uint64_t* out) {
+  using Fd = Field<F>;
+  memset(out, 0, 32);
+  if (n == 0) return KZG_OK;
+  if (n >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "vector too long");
+  std::vector<uint32_t> m{(uint32_t)n};
+  while (m.back() > 1) m.push_back((m.back() + LC - 1) / LC);
+  const size_t nl = m.size();
+  std::vector<uint32_t> hs(nl * F::N);
+  Fe<F> zp = Fd::to_mont(Fd::from_words(z_words));
+  for (size_t l = 0; l < nl; ++l) {
+    memcpy(&hs[l * F::N], zp.l, F::N * 4);
+    for (int q = 0; q < 5; ++q) zp = Fd::mul(zp, zp);
+  }
+  size_t total = 0;
+  for (size_t l = 1; l < nl; ++l) total += m[l];
+  int rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[2], (total + 1) * F::N * 4))) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[3], (nl + 2) * F::N * 4 + 64))) return rc;
+  uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
+  uint32_t* d_zp = static_cast<uint32_t*>(c->poly_tmp[3].p);
+  uint32_t* d_out = d_zp + (nl + 1) * F::N;
+  d_out += (8 - ((uintptr_t)d_out / 4) % 8) % 8;      // 32-byte alignment for the uint4 store
+  KZG_HIP(c, hipMemcpyAsync(d_zp, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  if (nl == 1) {     // n == 1: the value is the coefficient itself
+    KZG_HIP(c, hipMemcpyAsync(out, a, 32, hipMemcpyDeviceToHost, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+    return KZG_OK;
+  }
+  std::vector<uint32_t*> hp(nl, nullptr);
+  { uint32_t* x = d_h; for (size_t l = 1; l < nl; ++l) { hp[l] = x; x += (size_t)m[l] * F::N; } }
+  hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, a, m[0],
+                     d_zp, hp[1]);
+  for (size_t l = 1; l + 1 < nl; ++l)
+    hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hp[l],
+                       m[l], d_zp + l * F::N, hp[l + 1]);
+  KZG_HIP(c, hipGetLastError());
+  // the top level holds one weak-normal value (standard form): canonicalise on the host
+  uint32_t top[F::N];
+  KZG_HIP(c, hipMemcpyAsync(top, hp[nl - 1], F::N * 4, hipMemcpyDeviceToHost, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  Fe<F> v;
+  memcpy(v.l, top, F::N * 4);
+  Fd::to_words(Fd::reduce(v), reinterpret_cast<uint32_t*>(out));
+  (void)d_out;
+  return KZG_OK;
+}
+
+}  // namespace
+
+#define KZG_FR_DISPATCH(fn, ...) (c->curve == 0 ? fn<BnFr>(__VA_ARGS__) : fn<BlsFr>(__VA_ARGS__))
+int fr_vec_binary(Ctx* c, int op, size_t n, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  return KZG_FR_DISPATCH(vec_binary_t, c, op, n, a, b, out);
+}
+int fr_vec_lincomb(Ctx* c, size_t n, size_t k, const uint32_t* const* ptrs, const size_t* lens, const uint32_t* scalars,
+                   uint32_t* out) {
+  return KZG_FR_DISPATCH(vec_lincomb_t, c, n, k, ptrs, lens, scalars, out);
+}
+int fr_vec_mul_powers(Ctx* c, size_t n, const uint32_t* a, const uint32_t* s, const uint32_t* cc, uint32_t* out) {
+  return KZG_FR_DISPATCH(vec_mul_powers_t, c, n, a, s, cc, out);
+}
+int fr_vec_inverse(Ctx* c, size_t n, const uint32_t* a, uint32_t* out) { return KZG_FR_DISPATCH(vec_inverse_t, c, n, a, out); }
+int fr_vec_prefix_product(Ctx* c, size_t n, const uint32_t* a, uint32_t* out) {
+  return KZG_FR_DISPATCH(vec_prefix_product_t, c, n, a, out);
+}
+int fr_poly_eval(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z, uint64_t* out) {
+  return KZG_FR_DISPATCH(poly_eval_t, c, n, a, z, out);
+}
+
+}  // namespace kzg

@@ -1,0 +1,282 @@
+"""PLONK prover with every polynomial resident in HBM -- BASELINE config 5 ("full plonk/prover.py
+round at n = 2^20 gates, all commits/NTTs on the GPU"), SURVEY.md section 8f N2.
+
+Same protocol, transcript and proof dictionary as kzg_snark_amd/plonk.py (and therefore the same
+Verifier); what changes is where the algebra runs.  The reference does the prover's polynomial
+algebra with Sage's dense polynomials on the host (plonk/prover.py:243-316: n-1 sequential field
+divisions for the accumulator, degree-3n products and a division by X^n - 1 for the quotient).
+Here:
+  * wire / accumulator polynomials: device INTTs (kzg_ntt_device);
+  * accumulator: ratios by batch inversion + exclusive prefix product (kzg_fr_vec_inverse,
+    kzg_fr_vec_prefix_product) instead of a sequential loop;
+  * quotient: every polynomial is evaluated on the coset K*H' of the size-4n subgroup (coefficient
+    shift + 4n-point NTT), the constraint is combined pointwise, divided by Z_H (which takes four
+    values on the coset) and interpolated back -- no dense products, no polynomial division;
+  * evaluations at zeta: kzg_fr_poly_eval; linearisation: kzg_fr_vec_lincomb;
+  * commitments / openings: kzg_commit_device / kzg_open_device.
+Vectors are int64[n, 4] torch tensors (canonical 32-byte Fr elements)."""
+import numpy as np
+import torch
+
+from . import _native
+from .kzg import KZG, CommitmentKey
+from .plonk import Domain
+from .transcript import Transcript
+
+
+class DeviceAlgebra:
+    """Thin helper around the C ABI's kzg_fr_* and NTT entry points for torch tensors."""
+
+    def __init__(self, curve_type, device="cuda:0"):
+        self.ctx = _native.get_context(curve_type)
+        self.dev = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.stream)        # every torch op of this thread shares the library's stream
+        self.ctx.set_stream(self.stream.cuda_stream)
+        self.r = KZG(curve_type).curve_order
+
+    # ---- construction
+    def upload(self, values):
+        arr = _native.ints_to_limbs([int(v) % self.r for v in values])
+        with torch.cuda.stream(self.stream):
+            return torch.from_numpy(arr.view(np.int64)).to(self.dev, non_blocking=False)
+
+    def download(self, t, count=None):
+        self.ctx.synchronize()
+        a = t[:count] if count is not None else t
+        return _native.limbs_to_ints(a.cpu().numpy().view(np.uint64))
+
+    def zeros(self, n):
+        with torch.cuda.stream(self.stream):
+            return torch.zeros((n, 4), dtype=torch.int64, device=self.dev)
+
+    def const(self, n, value):
+        with torch.cuda.stream(self.stream):
+            row = torch.from_numpy(_native.int_to_words(int(value) % self.r).view(np.int64)).to(self.dev)
+            return row.repeat(n, 1).contiguous()
+
+    def padded(self, t, n):
+        with torch.cuda.stream(self.stream):
+            out = torch.zeros((n, 4), dtype=torch.int64, device=self.dev)
+            out[:t.shape[0]] = t
+            return out
+
+    # ---- element-wise
+    def op(self, kind, a, b):
+        out = torch.empty_like(a)
+        self.ctx.vec_op(kind, a.shape[0], a.data_ptr(), b.data_ptr(), out.data_ptr())
+        return out
+
+    def mul(self, a, b): return self.op("mul", a, b)
+    def add(self, a, b): return self.op("add", a, b)
+    def sub(self, a, b): return self.op("sub", a, b)
+
+    def lincomb(self, n, terms):
+        """sum_j s_j * v_j over the first n entries; terms = [(scalar, tensor), ...]."""
+        out = torch.empty((n, 4), dtype=torch.int64, device=self.dev)
+        self.ctx.vec_lincomb(n, [t.data_ptr() for _, t in terms], [min(t.shape[0], n) for _, t in terms],
+                             [int(s) % self.r for s, _ in terms], out.data_ptr())
+        return out
+
+    def mul_powers(self, a, s, c0=1):
+        out = torch.empty_like(a)
+        self.ctx.vec_mul_powers(a.shape[0], a.data_ptr(), int(s) % self.r, int(c0) % self.r, out.data_ptr())
+        return out
+
+    def inverse(self, a):
+        out = torch.empty_like(a)
+        self.ctx.vec_inverse(a.shape[0], a.data_ptr(), out.data_ptr())
+        return out
+
+    def prefix_product(self, a):
+        out = torch.empty_like(a)
+        self.ctx.vec_prefix_product(a.shape[0], a.data_ptr(), out.data_ptr())
+        return out
+
+    def eval(self, coeffs, z):
+        return self.ctx.poly_eval(coeffs.shape[0], coeffs.data_ptr(), int(z) % self.r)
+
+    def ntt(self, t, w, inverse):
+        n = t.shape[0]
+        self.ctx.ntt_device(t.data_ptr(), n.bit_length() - 1, _native.int_to_words(int(w) % self.r), inverse, 1)
+        return t
+
+    def set_entries(self, t, updates):
+        """t[i] = (t[i] + delta) mod r for a handful of (i, delta) pairs (blinding terms)."""
+        self.ctx.synchronize()
+        for i, delta in updates:
+            cur = _native.limbs_to_ints(t[i:i + 1].cpu().numpy().view(np.uint64))[0]
+            row = _native.int_to_words((cur + int(delta)) % self.r).view(np.int64)
+            with torch.cuda.stream(self.stream):
+                t[i] = torch.from_numpy(row).to(self.dev)
+
+
+class DeviceIndexer:
+    def __init__(self, curve_type="bls12_381"):
+        self.kzg = KZG(curve_type)
+        self.alg = DeviceAlgebra(curve_type)
+
+    def preprocess(self, qM, qL, qR, qO, qC, perm, tau=None):
+        kzg, Fq, alg = self.kzg, self.kzg.Fq, self.alg
+        dom = Domain(Fq, len(qM))
+        n = dom.n
+        assert len(qM) == n and len(perm) == 3 * n, "pad the circuit to a power of two first"
+        ck, rk = kzg.setup(n + 5, tau=tau)                                           # main.py:85
+        sstar = dom.sigma_star(perm)
+        cols = {"qM": qM, "qL": qL, "qR": qR, "qO": qO, "qC": qC,
+                "S_sigma1": sstar[:n], "S_sigma2": sstar[n:2 * n], "S_sigma3": sstar[2 * n:]}
+        coeffs = {k: alg.ntt(alg.upload(v), dom.g, True) for k, v in cols.items()}     # 8 INTTs
+        pack = torch.stack([coeffs[k] for k in cols]).contiguous()
+        xy, inf = alg.ctx.commit_device(ck.srs, pack.data_ptr(), [n] * len(cols), n)  # 8 MSMs
+        comms = dict(zip(cols, kzg._points(xy, inf)))
+        sub = {"n": n, "g": dom.g, "k1": dom.k1, "k2": dom.k2}
+        ipk = {"ck": ck, "coeffs": coeffs, "sigma_values": {k: alg.upload(cols[k]) for k in
+                                                            ("S_sigma1", "S_sigma2", "S_sigma3")},
+               "subgroups": sub, "commitments": comms}
+        ivk = {"rk": rk, "commitments": comms, "subgroups": sub}
+        return ipk, ivk
+
+
+class DeviceProver:
+    def __init__(self, curve_type="bls12_381", alg=None):
+        self.kzg = KZG(curve_type)
+        self.alg = alg or DeviceAlgebra(curve_type)
+
+    def _commit(self, ck, tensors):
+        alg = self.alg
+        stride = max(t.shape[0] for t in tensors)
+        pack = torch.stack([alg.padded(t, stride) for t in tensors]).contiguous()
+        xy, inf = alg.ctx.commit_device(ck.srs, pack.data_ptr(), [t.shape[0] for t in tensors], stride)
+        return self.kzg._points(xy, inf), pack
+
+    def _blind(self, coeffs, n, blinders):
+        """coeffs (length n) + (b_k X^k + ... + b_0) * (X^n - 1): length n + len(blinders)."""
+        alg = self.alg
+        out = alg.padded(coeffs, n + len(blinders))
+        ups = []
+        for k, bk in enumerate(blinders):            # blinders[k] multiplies X^k
+            ups.append((k, -int(bk)))
+            ups.append((n + k, int(bk)))
+        alg.set_entries(out, ups)
+        return out
+
+    def prove(self, ipk, x, w):
+        kzg, Fq, alg = self.kzg, self.kzg.Fq, self.alg
+        r = kzg.curve_order
+        ck, C = ipk["ck"], ipk["coeffs"]
+        sub = ipk["subgroups"]
+        n, g, k1, k2 = sub["n"], sub["g"], sub["k1"], sub["k2"]
+        assert isinstance(ck, CommitmentKey)
+        dom = Domain.__new__(Domain)                 # reuse lagrange_1_at without rebuilding H
+        dom.Fq, dom.n, dom.g = Fq, n, g
+        tr = Transcript("plonk-proof", Fq)
+        tr.append_message("public-inputs", x)
+        full = [int(v) % r for v in list(x) + list(w)]
+        assert len(full) == 3 * n
+        b = [int(Fq.random_element()) for _ in range(11)]
+        ones = alg.const(n, 1)
+        idH = alg.mul_powers(ones, g)                                         # g^i
+
+        # round 1
+        vals = [alg.upload(full[i * n:(i + 1) * n]) for i in range(3)]
+        wires = [self._blind(alg.ntt(v.clone(), g, True), n, [b[2 * i + 1], b[2 * i]]) for i, v in enumerate(vals)]
+        a_c, b_c, c_c = wires
+        wire_comms, _ = self._commit(ck, wires)
+        tr.append_message("round1-commitments", wire_comms)
+        beta, gamma = int(tr.get_challenge("beta")), int(tr.get_challenge("gamma"))
+
+        # round 2: z_i = prod_{j<i} num_j / den_j
+        S = ipk["sigma_values"]
+        num = den = None
+        for v, shift, sig in ((vals[0], 1, S["S_sigma1"]), (vals[1], int(k1), S["S_sigma2"]), (vals[2], int(k2), S["S_sigma3"])):
+            fn = alg.lincomb(n, [(1, v), (beta * shift, idH), (gamma, ones)])
+            fd = alg.lincomb(n, [(1, v), (beta, sig), (gamma, ones)])
+            num = fn if num is None else alg.mul(num, fn)
+            den = fd if den is None else alg.mul(den, fd)
+        z_vals = alg.prefix_product(alg.mul(num, alg.inverse(den)))
+        z_c = self._blind(alg.ntt(z_vals, g, True), n, [b[8], b[7], b[6]])
+        z_comm = self._commit(ck, [z_c])[0][0]
+        tr.append_message("round2-commitment", z_comm)
+        alpha = int(tr.get_challenge("alpha"))
+
+        # round 3: quotient on the coset K * H', |H'| = 4n
+        N4 = 4 * n
+        w4 = int(Fq.root_of_unity(N4))
+        K = int(Fq.multiplicative_generator())
+
+        def on_coset(coeffs):
+            return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
+
+        pi_vals = [(-int(v)) % r for v in x] + [0] * (n - len(x))
+        PI_c = alg.ntt(alg.upload(pi_vals), g, True)
+        E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("z", z_c), ("PI", PI_c))}
+        for k in ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3"):
+            E[k] = on_coset(C[k])
+        ones4 = alg.const(N4, 1)
+        xs = alg.mul_powers(ones4, w4, K)                                     # the coset points
+        zw = torch.roll(E["z"], shifts=-4, dims=0).contiguous()              # z(g * x): g = w4^4
+        gate = alg.add(alg.add(alg.mul(alg.mul(E["a"], E["b"]), E["qM"]), alg.mul(E["a"], E["qL"])),
+                       alg.add(alg.mul(E["b"], E["qR"]), alg.mul(E["c"], E["qO"])))
+        gate = alg.add(gate, alg.add(E["PI"], E["qC"]))
+        p1 = p2 = None
+        for key, shift, sig in (("a", 1, "S_sigma1"), ("b", int(k1), "S_sigma2"), ("c", int(k2), "S_sigma3")):
+            f1 = alg.lincomb(N4, [(1, E[key]), (beta * shift, xs), (gamma, ones4)])
+            f2 = alg.lincomb(N4, [(1, E[key]), (beta, E[sig]), (gamma, ones4)])
+            p1 = f1 if p1 is None else alg.mul(p1, f1)
+            p2 = f2 if p2 is None else alg.mul(p2, f2)
+        perm = alg.sub(alg.mul(p1, E["z"]), alg.mul(p2, zw))
+        # Z_H(x) = x^n - 1 and L1(x) = Z_H(x) / (n (x - 1)) on the coset
+        xn = alg.mul_powers(ones4, pow(w4, n, r), pow(K, n, r))                # x^n: four distinct values
+        zh = alg.sub(xn, ones4)
+        l1 = alg.mul(zh, alg.inverse(alg.lincomb(N4, [(n, xs), (-n, ones4)])))
+        l1t = alg.mul(alg.sub(E["z"], ones4), l1)
+        numer = alg.lincomb(N4, [(1, gate), (alpha, perm), (alpha * alpha, l1t)])
+        t_ev = alg.mul(numer, alg.inverse(zh))
+        t_c = alg.mul_powers(alg.ntt(t_ev, w4, True), pow(K, -1, r))          # back to coefficients
+        tail = alg.download(t_c[3 * n + 6:3 * n + 6 + 64])
+        assert not any(tail), "constraint system is not satisfied (quotient has a remainder)"
+        t_lo = alg.padded(t_c[:n], n + 1)
+        t_mid = alg.padded(t_c[n:2 * n], n + 1)
+        t_hi = t_c[2 * n:3 * n + 6].clone()
+        alg.set_entries(t_lo, [(n, b[9])])
+        alg.set_entries(t_mid, [(0, -b[9]), (n, b[10])])
+        alg.set_entries(t_hi, [(0, -b[10])])
+        t_comms, _ = self._commit(ck, [t_lo, t_mid, t_hi])
+        tr.append_message("round3-commitments", t_comms)
+        zeta = int(tr.get_challenge("zeta"))
+
+        # round 4
+        ev = {"a": alg.eval(a_c, zeta), "b": alg.eval(b_c, zeta), "c": alg.eval(c_c, zeta),
+              "s_sigma1": alg.eval(C["S_sigma1"], zeta), "s_sigma2": alg.eval(C["S_sigma2"], zeta),
+              "z_omega": alg.eval(z_c, zeta * int(g) % r)}
+        evF = {k: Fq(v) for k, v in ev.items()}
+        tr.append_message("round4-evaluations", [evF[k] for k in ("a", "b", "c", "s_sigma1", "s_sigma2", "z_omega")])
+        v = int(tr.get_challenge("v"))
+
+        # round 5: r(X) as a scalar combination of coefficient vectors
+        za, zb, zc, s1, s2, zo = (ev[k] for k in ("a", "b", "c", "s_sigma1", "s_sigma2", "z_omega"))
+        zn = pow(zeta, n, r)
+        L1z = int(dom.lagrange_1_at(Fq(zeta)))
+        PIz = alg.eval(PI_c, zeta)
+        f1 = (za + beta * zeta + gamma) * (zb + beta * int(k1) * zeta + gamma) * (zc + beta * int(k2) * zeta + gamma) % r
+        f2 = (za + beta * s1 + gamma) * (zb + beta * s2 + gamma) * zo % r
+        e0 = alg.const(1, 1)
+        const = (PIz - alpha * f2 * (zc + gamma) - alpha * alpha * L1z) % r
+        r_c = alg.lincomb(n + 6, [
+            (za * zb, C["qM"]), (za, C["qL"]), (zb, C["qR"]), (zc, C["qO"]), (1, C["qC"]), (const, e0),
+            (alpha * f1 + alpha * alpha * L1z, z_c), (-alpha * f2 * beta, C["S_sigma3"]),
+            (-(zn - 1), t_lo), (-(zn - 1) * zn, t_mid), (-(zn - 1) * zn * zn, t_hi)])
+        assert alg.eval(r_c, zeta) == 0, "r(zeta) should be zero"                       # plonk/prover.py:171
+        polys = [r_c, a_c, b_c, c_c, C["S_sigma1"], C["S_sigma2"]]
+        stride = n + 6
+        pack = torch.stack([alg.padded(p, stride) for p in polys]).contiguous()
+        zw_ = _native.int_to_words
+        xy, inf, _ = alg.ctx.open(ck.srs, pack.data_ptr(), [p.shape[0] for p in polys], stride, zw_(zeta), zw_(v), device=True)
+        W_z = kzg._points(xy, inf)[0]
+        zpack = alg.padded(z_c, stride)
+        xy, inf, _ = alg.ctx.open(ck.srs, zpack.data_ptr(), [z_c.shape[0]], stride, zw_(zeta * int(g) % r), zw_(v), device=True)
+        W_zw = kzg._points(xy, inf)[0]
+        return {"commitments": dict(zip(("a", "b", "c"), wire_comms), z=z_comm,
+                                    t_lo=t_comms[0], t_mid=t_comms[1], t_hi=t_comms[2]),
+                "evaluations": evF,
+                "kzg_proofs": {"W_z": W_z, "W_zw": W_zw}}

@@ -111,3 +111,31 @@ def test_round_trip_on_the_engine(curve, gates):
     from kzg_snark_amd.field import GF
     circuit = fixture_instance() if gates is None else plonk.synthetic_circuit(gates, GF(O.curve(curve).r), seed=7)
     round_trip(lambda c: KZG(c), circuit, curve)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve,gates", [("bn254", None), ("bls12_381", 64), ("bls12_381", 4096)])
+def test_device_prover_round_trip(curve, gates):
+    """kzg_snark_amd/plonk_device.py: the same protocol with every polynomial resident in HBM
+    (coset-NTT quotient, batch-inverse accumulator).  Its proofs must satisfy the host Verifier."""
+    from kzg_snark_amd import plonk, plonk_device
+    from kzg_snark_amd.field import GF
+    Fq = GF(O.curve(curve).r)
+    if gates is None:
+        qM, qL, qR, qO, qC, perm, x, w = fixture_instance()
+    else:
+        qM, qL, qR, qO, qC, perm, x, w = plonk.synthetic_circuit(gates, Fq, seed=gates)
+    idx = plonk_device.DeviceIndexer(curve)
+    ipk, ivk = idx.preprocess(qM, qL, qR, qO, qC, perm)
+    prv = plonk_device.DeviceProver(curve, alg=idx.alg)
+    proof = prv.prove(ipk, x, w)
+    ver = plonk.Verifier(curve)
+    assert ver.verify(ivk, x, proof)
+    bad = dict(proof)
+    bad["evaluations"] = dict(proof["evaluations"])
+    bad["evaluations"]["c"] = proof["evaluations"]["c"] + 1
+    assert not ver.verify(ivk, x, bad)
+    w2 = list(w)
+    w2[len(w2) // 2] = int(w2[len(w2) // 2]) + 1
+    with pytest.raises(AssertionError):
+        prv.prove(ipk, x, w2)                      # unsatisfied witness: the quotient has a remainder

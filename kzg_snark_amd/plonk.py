@@ -25,7 +25,9 @@ class Domain:
         self.Fq = Fq
         self.n = 1 << max(0, (n_gates - 1).bit_length())
         self.g = Fq.root_of_unity(self.n)
-        self.H = [self.g ** i for i in range(self.n)]
+        self.H = [Fq(1)]
+        for _ in range(self.n - 1):
+            self.H.append(self.H[-1] * self.g)
         n, ks = self.n, []
         cand = 2
         while len(ks) < 2:

@@ -9,8 +9,9 @@ and key dictionary shapes (plonk/prover.py:188-210, plonk/indexer.py:92-118), 4 
 of size n+2..n+6 per proof plus two openings.
 
 Polynomial algebra here is the host shim (schoolbook products): fine for the reference's 16-gate
-fixture and the small synthetic circuits of the tests.  The n = 2^20 round needs the quotient on
-the device (coset NTTs of size 4n instead of dense products) -- the next step of this row."""
+fixture and the small synthetic circuits of the tests.  The n = 2^20 round runs in
+plonk_device.py, where the quotient is computed on the device (coset NTTs of size 4n instead of
+dense products); both provers share this module's Verifier."""
 from .fft_ff import fft_ff_interpolation
 from .kzg import KZG
 from .transcript import Transcript

@@ -35,13 +35,17 @@
 // it canonical.
 #include "internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace kzg {
 
 namespace {
 
-constexpr int TILE_LOG = 12;            // elements per LDS tile (4096 * 36 B = 144 KiB)
+constexpr int TILE_LOG = 12;            // largest LDS tile: 4096 elements * 36 B = 144 KiB (one workgroup per CU)
+constexpr int TILE_LOG_2WG = 11;        // preferred tile: 2048 elements = 72 KiB, TWO workgroups per CU, so one
+                                        // workgroup's HBM load/store phases overlap the other's butterfly levels
+                                        // (SQ counters of the one-per-CU version: 44 % of wave cycles parked)
 constexpr int FRN = 9;                  // limbs of both scalar fields
 
 struct NttPassArgs {
@@ -61,6 +65,7 @@ struct NttPassArgs {
   uint64_t ld_line, ld_pos, tile_ld;
   uint64_t st_line, st_pos, tile_st;
   uint64_t batch_stride;   // elements between transforms of a batch (blockIdx.y)
+  uint32_t pair_tiles;     // g > 0: remap blockIdx so that each group of 2^g adjacent tiles lands on one XCD
 };
 
 // LDS word address of element `pos` of line `line`.  Elements are 9 words; one
@@ -98,7 +103,14 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t k = a.k, logC = a.logC;
   const uint32_t LEN = 1u << k, C = 1u << logC, TILE = LEN << logC;
-  const uint64_t tile = blockIdx.x;
+  // Adjacent tiles share 128-byte lines when a tile holds fewer than 4 columns; workgroups b and
+  // b + 8 run on the same XCD (round-robin dispatch), so give them adjacent tiles (speed only).
+  uint64_t tile = blockIdx.x;
+  if (a.pair_tiles) {          // groups of 2^g tiles (g = pair_tiles) on one XCD
+    const uint32_t g = a.pair_tiles, span = 3 + g;
+    const uint32_t q = blockIdx.x >> span, rr = blockIdx.x & ((1u << span) - 1);
+    tile = ((uint64_t)q << span) + ((rr & 7) << g) + (rr >> 3);
+  }
   const uint32_t* src = a.src + (a.batch_stride * blockIdx.y + tile * a.tile_ld) * 8;
   uint32_t* dst = a.dst + (a.batch_stride * blockIdx.y + tile * a.tile_st) * 8;
 
@@ -276,13 +288,23 @@ int build_domain(Ctx* c, NttDomain& d) {
   return KZG_OK;
 }
 
+// preferred log2(tile elements): KZG_NTT_TILE_LOG = 10 | 11 | 12 (experiments); default 11
+static uint32_t tile_log_pref() {
+  static const uint32_t v = [] {
+    const char* e = getenv("KZG_NTT_TILE_LOG");
+    const int x = e ? atoi(e) : TILE_LOG_2WG;
+    return (uint32_t)std::min(std::max(x, 8), TILE_LOG);
+  }();
+  return v;
+}
+
 template <class F>
 int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) {
   const uint32_t log_n = d.log_n;
   const uint64_t n = 1ull << log_n;
   auto launch = [&](const NttPassArgs& a, uint64_t tiles) -> int {
     const uint32_t tile_elems = 1u << (a.k + a.logC);
-    const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2));
+    const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 4));
     const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
     static bool lds_attr_set = false;   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
     if (!lds_attr_set) {
@@ -298,6 +320,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   if (log_n <= (uint32_t)TILE_LOG) {
     NttPassArgs a{};
     a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
+    a.pair_tiles = 0;
     a.scale = d.d_scale; a.k = log_n; a.logC = 0; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
     a.c_fast_store = 1; a.col_base = 0;
     a.ld_line = 0; a.ld_pos = 1; a.tile_ld = 0; a.st_line = 0; a.st_pos = 1; a.tile_st = 0;
@@ -310,8 +333,10 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   if (rc) return rc;
   uint32_t* scratch = static_cast<uint32_t*>(c->ntt_scratch.p);
   {  // pass 1: columns of the N1 x N2 matrix, twist by w^(t*v)
-    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, k2);
+    const uint32_t tl = std::max<uint32_t>(k1, tile_log_pref());
+    const uint32_t logC = std::min<uint32_t>(tl - k1, k2);
     NttPassArgs a{};
+    a.pair_tiles = (logC < 2 && ((N2 >> logC) % (8u << (2 - logC)) == 0)) ? 2 - logC : 0;
     a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twist = d.d_twist; a.twist_pitch = N2;
     a.scale = nullptr;
     a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1; a.c_fast_store = 1; a.col_base = 0;
@@ -322,8 +347,10 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     if (rc) return rc;
   }
   {  // pass 2: rows; row t, output index b -> out[b*N1 + t]
-    const uint32_t logC = std::min<uint32_t>(TILE_LOG - k2, k1);
+    const uint32_t tl = std::max<uint32_t>(k2, tile_log_pref());
+    const uint32_t logC = std::min<uint32_t>(tl - k2, k1);
     NttPassArgs a{};
+    a.pair_tiles = (logC < 2 && ((N1 >> logC) % (8u << (2 - logC)) == 0)) ? 2 - logC : 0;
     a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.scale = d.d_scale;
     a.k = k2; a.logC = logC; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0; a.c_fast_store = 1; a.col_base = 0;
@@ -359,6 +386,7 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
   while ((1ull << (lc + 1)) <= count) ++lc;
   NttPassArgs a{};
   a.src = d_data; a.dst = d_data; a.stage = dom->d_stage; a.kmax = dom->kmax; a.h = 0; a.batch_stride = 0;
+  a.pair_tiles = 0;
   uint64_t tiles;
   if (!rows_pass) {
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, lc);

@@ -9,6 +9,9 @@ and a GPU these raise kzg_snark_amd._native.NativeUnavailable.
 
 `F` may be a kzg_snark_amd.field.PrimeField or any object answering order()
 (a Sage GF); elements may be anything int() accepts.  Outputs are F(x) elements.
+A numpy uint64[n, 4] array of canonical little-endian limbs is also accepted (and
+returned) by fft_ff / ifft_ff: the buffer fast path that skips per-element
+Python-object conversion.
 """
 import numpy as np
 
@@ -30,6 +33,15 @@ def _curve_for(F):
 
 def _transform(seq, w, F, inverse):
     n = len(seq)
+    if isinstance(seq, np.ndarray) and seq.dtype == np.uint64 and seq.ndim == 2 and seq.shape[1] == 4:
+        # buffer fast path (Python-object marshalling costs far more than the
+        # transform): canonical little-endian limbs in, a new array of the same shape out
+        if n & (n - 1):
+            raise ValueError(f"fft_ff: length {n} is not a power of two")
+        curve, r = _curve_for(F)
+        data = np.ascontiguousarray(seq).copy()
+        _native.get_context(curve).ntt(data, n.bit_length() - 1, _native.int_to_words(int(w) % r), inverse)
+        return data
     if n & (n - 1):
         # The reference recursion silently mis-sizes odd splits (fft_ff.py:20-21 with
         # result = [F(0)]*n) and returns values that are not a transform of anything;

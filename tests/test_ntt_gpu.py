@@ -134,6 +134,10 @@ def test_facade_signatures(native):
     for i in range(16):
         p2 = fft_ff_interpolation(vals, g, F)
         assert p2(g ** i) == vals[i]
+    arr = native.ints_to_limbs([int(v) for v in vals])       # buffer fast path: limbs in, limbs out
+    out = fft_ff(arr, g, F)
+    assert isinstance(out, np.ndarray) and native.limbs_to_ints(out) == [int(v) for v in ev]
+    assert np.array_equal(ifft_ff(out, g, F), arr)
     with pytest.raises(AssertionError):
         fft_ff_interpolation(vals[:12], g, F)              # fft_ff.py:74
     with pytest.raises(AssertionError):

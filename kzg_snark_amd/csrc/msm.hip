@@ -599,19 +599,16 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
                        : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
 }
 
-// Commit pipeline: three stages on three internal streams, up to four polynomials in flight.
+// Commit pipeline: three stages on three internal streams, three polynomials in flight.
 //   P  prep        digits, sort, bounds, bucket order, slices      (memory-bound)
 //   A  accumulate  the mixed-addition kernel                        (ALU-bound)
 //   B  reduce      finalize, row/column sums, bit planes, copy-out  (latency-bound)
-// Scheduling (measured with rocprofv3 timelines): the memory-bound prep and the ALU-bound accumulate
-// slow each other down when they share the machine (prep ran at 1/6 speed), so polynomials are
-// processed in groups: all preps of a group back to back, then all accumulates back to back, the
-// latency-bound reduce of each polynomial overlapping whatever follows it.  The context's stream only
+// prep(p+1), accumulate(p) and reduce(p-1) run concurrently.  The context's stream only
 // carries ordering: P waits for everything enqueued on it before the call (the scalars), and it
 // waits for P to have consumed the scalars, so later work on the context's stream (the next NTT)
 // can neither race with prep nor queue behind accumulate.  Every buffer belongs to a slot; the
 // host finishes a polynomial (Horner + one inversion) when its slot is recycled or on flush.
-constexpr int NSLOT = 4;
+constexpr int NSLOT = 3;
 
 struct MsmSlot {
   DevBuf keys_a, keys_b, vals_a, vals_b, bstart, lkey_a, lkey_b, lval_a, ns;       // prep
@@ -623,8 +620,6 @@ struct MsmSlot {
   hipEvent_t ev_b = nullptr;   // reduce done (h_tb ready)
   bool pending = false;
   int win_bits = 0;
-  uint32_t n = 0;              // scalars of the polynomial in this slot
-  const Srs* srs = nullptr;
   uint64_t* out_xy = nullptr;
   uint8_t* out_inf = nullptr;
 };
@@ -634,7 +629,7 @@ struct MsmWork {
   MsmSlot slot[NSLOT];
   hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_a = nullptr, stream_b = nullptr;
   int next = 0;
-  int last_acc = -1;           // slot whose accumulate was enqueued last (the next group's prep waits for it)
+  int prev = -1;               // slot of the previously enqueued polynomial
 };
 
 static MsmWork* get_work(Ctx* c) {
@@ -661,8 +656,7 @@ void msm_free_work(Ctx* c) {
 }
 
 template <class C, int WB>
-static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, int slot_idx,
-                       int phase, int group_last_prep) {
+static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, int slot_idx) {
   using W = Win<WB>;
   using Key = typename W::Key;
   constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
@@ -735,12 +729,15 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   DevBuf& tmp = w->sort_tmp[slot_idx];
   if ((rc = ensure_buf(c, tmp, tmp_bytes))) return rc;
 
-  static const bool phased = [] { const char* e = getenv("KZG_MSM_PHASED"); return !(e && atoi(e) == 0); }();
-  if (phase == 1) goto accumulate_phase;
-  sl.n = n;
-  sl.srs = s;
-  if (phased && w->last_acc >= 0)       // this group's preps start when the previous group's accumulates are done
-    KZG_HIP(c, hipStreamWaitEvent(sp, w->slot[w->last_acc].ev_a, 0));
+  // Optional schedule  A(p) | prep(p+1) || reduce(p) | A(p+1)  (KZG_MSM_SERIAL=1): keeps the
+  // accumulate kernel alone on the machine.  Measured slower (287 vs 309 commits/s) than letting
+  // the three stages run freely, so it is off by default.
+  static const bool serial = [] { const char* e = getenv("KZG_MSM_SERIAL"); return e && atoi(e) == 1; }();
+  if (serial && w->prev >= 0 && w->prev != slot_idx) {
+    KZG_HIP(c, hipStreamWaitEvent(sp, w->slot[w->prev].ev_a, 0));   // prep(p+1) after accumulate(p)
+    KZG_HIP(c, hipStreamWaitEvent(sa, w->slot[w->prev].ev_b, 0));   // accumulate(p+1) after reduce(p)
+  }
+  w->prev = slot_idx;
 
   // ---- stage P: prep
   KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));
@@ -770,13 +767,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   KZG_HIP(c, hipEventRecord(sl.ev_p, sp));
   KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
 
-  return KZG_OK;
-
-accumulate_phase:
   // ---- stage A: accumulate
   KZG_HIP(c, hipStreamWaitEvent(sa, sl.ev_p, 0));
-  if (phased && group_last_prep >= 0) KZG_HIP(c, hipStreamWaitEvent(sa, w->slot[group_last_prep].ev_p, 0));
-  w->last_acc = slot_idx;
   {
     ProfScope ps(c, "msm_accumulate", sa);
     hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
@@ -880,38 +872,24 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     if (lens[p] > stride) return set_err(c, KZG_ERR_ARG, "kzg_commit: lens[p] > stride");
   }
   int rc = KZG_OK;
-  size_t p = 0;
-  while (p < n_polys && rc == KZG_OK) {
-    // one group: up to NSLOT polynomials -- all preps, then all accumulates (+ reduce)
-    int group[NSLOT];
-    int gcount = 0;
-    for (; p < n_polys && gcount < NSLOT && rc == KZG_OK; ++p) {
-      uint64_t* o = out_xy + p * 2 * (F::NW / 2);
-      if (lens[p] == 0) {   // zero polynomial: Z1 (kzg.py:109)
-        memset(o, 0, 2 * F::NW * 4);
-        out_inf[p] = 1;
-        continue;
-      }
-      const int si = w->next;
-      MsmSlot& sl = w->slot[si];
-      w->next = (w->next + 1) % NSLOT;
-      if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its reduce stage has long finished
-      const uint32_t* sc = d_scalars + p * stride * 8;
-      rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, si, 0, -1)
-                             : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, si, 0, -1);
-      if (rc) break;
-      sl.pending = true;
-      sl.out_xy = o;
-      sl.out_inf = out_inf + p;
-      group[gcount++] = si;
+  for (size_t p = 0; p < n_polys && rc == KZG_OK; ++p) {
+    uint64_t* o = out_xy + p * 2 * (F::NW / 2);
+    if (lens[p] == 0) {   // zero polynomial: Z1 (kzg.py:109)
+      memset(o, 0, 2 * F::NW * 4);
+      out_inf[p] = 1;
+      continue;
     }
-    for (int g = 0; g < gcount && rc == KZG_OK; ++g) {
-      const int si = group[g];
-      MsmSlot& sl = w->slot[si];
-      const int last_prep = (g == 0) ? group[gcount - 1] : -1;
-      rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, nullptr, sl.n, w, si, 1, last_prep)
-                             : msm_enqueue<C, 16>(c, s, nullptr, sl.n, w, si, 1, last_prep);
-    }
+    const int si = w->next;
+    MsmSlot& sl = w->slot[si];
+    w->next = (w->next + 1) % NSLOT;
+    if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
+    const uint32_t* sc = d_scalars + p * stride * 8;
+    rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, si)
+                           : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, si);
+    if (rc) break;
+    sl.pending = true;
+    sl.out_xy = o;
+    sl.out_inf = out_inf + p;
   }
   if (drain || rc != KZG_OK) {
     int r2 = commit_flush_t<C>(c);

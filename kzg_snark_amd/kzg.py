@@ -184,6 +184,40 @@ class KZG:
         tau_G2 = self.multiply(self.G2, tau)                                         # kzg.py:75
         return (CommitmentKey(ctx, srs), tau_G2)
 
+    # ---- on-disk commitment key: build the SRS once, reload it later -----------
+    #   bytes 0..7   magic b"KZGSRS1\0"      bytes 8..11  curve id (u32 LE: 0 bn254, 1 bls12_381)
+    #   bytes 12..15 uint64 limbs per coordinate (u32 LE)   bytes 16..23 number of points n (u64 LE)
+    #   then n * 2 * limbs little-endian uint64 (affine x | y, canonical), then n infinity-flag bytes
+    _MAGIC = b"KZGSRS1\0"
+
+    def save_key(self, ck, path, chunk=1 << 16):
+        key = self._key(ck)
+        ctx = self._context()
+        n, L = len(key), ctx.fp_limbs
+        with open(path, "wb") as f:
+            f.write(self._MAGIC)
+            f.write(int(ctx.curve_id).to_bytes(4, "little") + int(L).to_bytes(4, "little") + int(n).to_bytes(8, "little"))
+            flags = []
+            for start in range(0, n, chunk):
+                xy, inf = key.srs.export(start, min(chunk, n - start))
+                f.write(np.ascontiguousarray(xy, dtype="<u8").tobytes())
+                flags.append(inf)
+            f.write(np.concatenate(flags).astype(np.uint8).tobytes())
+
+    def load_key(self, path):
+        ctx = self._context()
+        with open(path, "rb") as f:
+            head = f.read(24)
+            if head[:8] != self._MAGIC:
+                raise ValueError("not a KZG SRS file")
+            cid, L, n = (int.from_bytes(head[8:12], "little"), int.from_bytes(head[12:16], "little"),
+                         int.from_bytes(head[16:24], "little"))
+            if cid != ctx.curve_id or L != ctx.fp_limbs:
+                raise ValueError("SRS file belongs to another curve")
+            xy = np.frombuffer(f.read(n * 2 * L * 8), dtype="<u8").reshape(n, 2 * L).astype(np.uint64)
+            inf = np.frombuffer(f.read(n), dtype=np.uint8).copy()
+        return CommitmentKey(ctx, ctx.srs_load_g1(np.ascontiguousarray(xy), inf))
+
     def commit(self, ck, polynomials):
         """kzg.py:80-120."""
         key = self._key(ck)

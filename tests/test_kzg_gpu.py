@@ -339,3 +339,18 @@ def test_sharded_open_and_commit_by_coefficient_range(native, kzgs, curve):
     assert (proof[0], proof[1]) == want
     assert ev0 == O.poly_eval(O.combine(polys, xi, cv.r), z, cv.r)
     assert (commit_sum[0], commit_sum[1]) == O.normalize(O.commit_trapdoor(polys[0], tau, cv), cv)
+
+
+def test_key_file_round_trip(kzgs, tmp_path):
+    """On-disk SRS format: save, reload, same points, same commitments."""
+    kzg = kzgs["bls12_381"]
+    ck, _ = kzg.setup(300, tau=987654321)
+    path = tmp_path / "srs.bin"
+    kzg.save_key(ck, str(path), chunk=128)
+    assert path.stat().st_size == 24 + 301 * (96 + 1)
+    ck2 = kzg.load_key(str(path))
+    assert len(ck2) == 301 and all(ck2[i] == ck[i] for i in (0, 1, 150, 300))
+    poly = list(range(1, 302))
+    assert kzg.commit(ck2, [poly]) == kzg.commit(ck, [poly])
+    with pytest.raises(ValueError):
+        kzgs["bn254"].load_key(str(path))

@@ -352,6 +352,33 @@ __global__ __launch_bounds__(128) KZG_ACC_ATTR void msm_accumulate_kernel(const 
   store_xyzz<C>(partials, t, acc);
 }
 
+// Skewed scalars (many equal or small coefficients) put thousands of slices into a few buckets.
+// Buckets come in length order, so those are the first ranks: the first HEAVY_RANKS ranks whose
+// slice count exceeds HEAVY_NS are folded by a whole 256-thread block each, the rest by FIN lanes.
+constexpr uint32_t HEAVY_RANKS = 256;
+constexpr uint32_t HEAVY_NS = 64;
+
+template <class C, int WB>
+__global__ __launch_bounds__(256) void msm_finalize_heavy_kernel(const uint32_t* partials, const uint32_t* order,
+                                                                 const uint32_t* slice_off, uint32_t* buckets) {
+  constexpr int N = C::Fp::N;
+  __shared__ uint32_t xch[3 * 4 * N];
+  const uint32_t r = blockIdx.x;
+  const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
+  if (p1 - p0 <= HEAVY_NS) return;                 // whole block exits together
+  XYZZ<C> acc = Ec<C>::infinity();
+  for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0 && wave) store_xyzz<C>(xch, wave - 1, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) acc = Ec<C>::add(acc, load_xyzz<C>(xch, k));
+    store_xyzz<C>(buckets, order[r], acc);
+  }
+}
+
 // FIN lanes per bucket (in length order) fold that bucket's slice partials
 template <class C, int WB>
 __global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* partials, const uint32_t* order,
@@ -360,13 +387,14 @@ __global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* parti
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = gt / FIN, g = gt % FIN;
   XYZZ<C> acc = Ec<C>::infinity();
-  if (r < NB) {
+  const bool heavy = r < HEAVY_RANKS && r < NB && slice_off[r + 1] - slice_off[r] > HEAVY_NS;   // other kernel
+  if (r < NB && !heavy) {
     const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
     for (uint32_t p = p0 + g; p < p1; p += FIN) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
   }
 #pragma unroll
   for (int m = 1; m < (int)FIN; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
-  if (r < NB && g == 0) store_xyzz<C>(buckets, order[r], acc);
+  if (r < NB && g == 0 && !heavy) store_xyzz<C>(buckets, order[r], acc);
 }
 
 // Row and column sums of the bucket matrix (entry v = hi*2^LO + lo is buckets[v-1]; v = 0 is
@@ -781,6 +809,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   KZG_HIP(c, hipStreamWaitEvent(sb, sl.ev_a, 0));
   {
     ProfScope ps(c, "msm_finalize", sb);
+    hipLaunchKernelGGL((msm_finalize_heavy_kernel<C, WB>), dim3(std::min<uint32_t>(HEAVY_RANKS, NB)), dim3(256), 0, sb,
+                       static_cast<uint32_t*>(sl.partials.p), order, slice_off, static_cast<uint32_t*>(sl.buckets.p));
     hipLaunchKernelGGL((msm_finalize_kernel<C, WB>), dim3((uint32_t)(((uint64_t)NB * W::FIN + 127) / 128)), dim3(128),
                        0, sb, static_cast<uint32_t*>(sl.partials.p), order, slice_off,
                        static_cast<uint32_t*>(sl.buckets.p));

@@ -354,3 +354,26 @@ def test_key_file_round_trip(kzgs, tmp_path):
     assert kzg.commit(ck2, [poly]) == kzg.commit(ck, [poly])
     with pytest.raises(ValueError):
         kzgs["bn254"].load_key(str(path))
+
+
+def test_skewed_scalars_2_20(native, kzgs):
+    """Heavy buckets at full size: all-ones (one bucket receives 2^20 entries) and {0,1,2}
+    coefficients (the PLONK-like case of SURVEY.md 8d).  Trapdoor identities."""
+    cv = O.BLS12_381
+    kzg = kzgs["bls12_381"]
+    n = 1 << 20
+    tau = 0x3141592653589793 % cv.r
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    ctx = native.get_context("bls12_381")
+    g = O.from_affine(cv.g1)
+    ones = np.zeros((n, 4), dtype=np.uint64)
+    ones[:, 0] = 1
+    xy, inf = ctx.commit(ck.srs, ones.reshape(1, n, 4), [n], n)
+    geo = (pow(tau, n, cv.r) - 1) * pow(tau - 1, -1, cv.r) % cv.r          # 1 + tau + ... + tau^(n-1)
+    assert tuple(native.limbs_to_ints(xy.reshape(2, 6))) == O.normalize(O.multiply(g, geo, cv), cv)
+    rs = np.random.RandomState(5)
+    small = np.zeros((n, 4), dtype=np.uint64)
+    small[:, 0] = rs.randint(0, 3, size=n)
+    xy, inf = ctx.commit(ck.srs, small.reshape(1, n, 4), [n], n)
+    coeffs = [int(v) for v in small[:, 0]]
+    assert tuple(native.limbs_to_ints(xy.reshape(2, 6))) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)

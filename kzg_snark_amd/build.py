@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkzg_mi355x.so")
-SOURCES = ["api.hip", "ntt.hip", "msm.hip", "poly.hip"]
+SOURCES = ["api.hip", "ntt.hip", "msm.hip", "msm_prep.hip", "poly.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -31,10 +31,11 @@
 #include <algorithm>
 #include <vector>
 #include <type_traits>
+#include <utility>
 #include "internal.h"
 #include "ec.h"
 #include "msm.h"
-#include <rocprim/rocprim.hpp>
+#include "msm_prep.h"
 
 namespace kzg {
 
@@ -51,8 +52,6 @@ struct Win {
   static constexpr int LO = WB / 2;                           // bucket matrix: 2^HI rows x 2^LO columns
   static constexpr int HI = WB - 1 - LO;
   static constexpr int NPART = HI + LO + 1;                   // points handed to the host
-  using Key = typename std::conditional<(WB <= 16), uint16_t, uint32_t>::type;
-  static constexpr Key SKIP = (Key)((1u << WB) - 1);          // sorts behind every bucket
 };
 constexpr int MAX_NPART = 24;
 
@@ -62,11 +61,13 @@ template <class C> struct Rec {
   static constexpr int FLAG = 2 * N;   // word index of the flags (bit 0: infinity)
 };
 
+// x, y and the flag word of a record (bit 0: point at infinity)
 template <class C>
-__device__ __forceinline__ void load_rec(const uint32_t* recs, size_t idx, Fe<typename C::Fp>& x,
-                                         Fe<typename C::Fp>& y) {
+__device__ __forceinline__ uint32_t load_rec(const uint32_t* recs, size_t idx, Fe<typename C::Fp>& x,
+                                             Fe<typename C::Fp>& y) {
   constexpr int N = C::Fp::N;
   const uint32_t* p = recs + idx * Rec<C>::WORDS;
+  uint32_t flag;
   constexpr int Q = (2 * N + 3) / 4;                 // 16-byte loads covering x and y
   uint32_t w[4 * Q];
   if constexpr (4 * Q <= Rec<C>::WORDS && (Rec<C>::WORDS % 4) == 0) {
@@ -76,6 +77,7 @@ __device__ __forceinline__ void load_rec(const uint32_t* recs, size_t idx, Fe<ty
       const uint4 v = q[i];
       w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
     }
+    if constexpr (Rec<C>::FLAG < 4 * Q) flag = w[Rec<C>::FLAG]; else flag = p[Rec<C>::FLAG];
   } else {
     const uint2* q = reinterpret_cast<const uint2*>(p);
 #pragma unroll
@@ -83,9 +85,11 @@ __device__ __forceinline__ void load_rec(const uint32_t* recs, size_t idx, Fe<ty
       const uint2 v = q[i];
       w[2 * i] = v.x; w[2 * i + 1] = v.y;
     }
+    flag = p[Rec<C>::FLAG];
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) { x.l[j] = w[j]; y.l[j] = w[N + j]; }
+  return flag;
 }
 
 template <class C>
@@ -100,21 +104,32 @@ __device__ __forceinline__ void store_rec(uint32_t* recs, size_t idx, const Fe<t
   p[Rec<C>::FLAG] = inf ? 1u : 0u;
 }
 
+// XYZZ points are 4*N words = a whole number of 16-byte quads; every array of them is 16-byte aligned
 template <class C>
 __device__ __forceinline__ XYZZ<C> load_xyzz(const uint32_t* base, size_t idx) {
   constexpr int N = C::Fp::N;
-  const uint32_t* p = base + idx * 4 * N;
+  static_assert((4 * N) % 4 == 0, "XYZZ must be a whole number of quads");
+  const uint4* p = reinterpret_cast<const uint4*>(base + idx * 4 * N);
+  uint32_t w[4 * N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const uint4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
   XYZZ<C> r;
 #pragma unroll
-  for (int j = 0; j < N; ++j) { r.x.l[j] = p[j]; r.y.l[j] = p[N + j]; r.zz.l[j] = p[2 * N + j]; r.zzz.l[j] = p[3 * N + j]; }
+  for (int j = 0; j < N; ++j) { r.x.l[j] = w[j]; r.y.l[j] = w[N + j]; r.zz.l[j] = w[2 * N + j]; r.zzz.l[j] = w[3 * N + j]; }
   return r;
 }
 template <class C>
 __device__ __forceinline__ void store_xyzz(uint32_t* base, size_t idx, const XYZZ<C>& v) {
   constexpr int N = C::Fp::N;
-  uint32_t* p = base + idx * 4 * N;
+  uint32_t w[4 * N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) { p[j] = v.x.l[j]; p[N + j] = v.y.l[j]; p[2 * N + j] = v.zz.l[j]; p[3 * N + j] = v.zzz.l[j]; }
+  for (int j = 0; j < N; ++j) { w[j] = v.x.l[j]; w[N + j] = v.y.l[j]; w[2 * N + j] = v.zz.l[j]; w[3 * N + j] = v.zzz.l[j]; }
+  uint4* p = reinterpret_cast<uint4*>(base + idx * 4 * N);
+#pragma unroll
+  for (int q = 0; q < N; ++q) p[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 template <class C>
 __device__ __forceinline__ XYZZ<C> shfl_xor_xyzz(const XYZZ<C>& v, int mask) {
@@ -249,108 +264,131 @@ __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, 
 
 // ---- commit pipeline ----------------------------------------------------------------
 
-// scalar i -> NWIN signed digits; entry e = j*n + i
-template <int WB>
-__global__ void msm_digits_kernel(const uint32_t* scalars, const uint32_t* recs_flags_base, uint32_t rec_words,
-                                  uint32_t flag_word, uint32_t n, uint32_t srs_n, typename Win<WB>::Key* keys,
-                                  uint32_t* vals) {
-  using W = Win<WB>;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
-  const uint4 lo4 = sp[0], hi4 = sp[1];
-  const uint32_t w[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
-  const bool pt_inf = recs_flags_base[(size_t)i * rec_words + flag_word] & 1u;
-  uint32_t carry = 0;
+// Record staging for the accumulate kernel: the 16-byte quads of a record that hold x, y and the
+// flag word go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so the next
+// record is in flight during the whole mixed addition although the kernel sits at its VGPR budget).
+// One wave-instruction writes 64 lanes x 16 B contiguously: the image of a wave is [quad][lane][4 words].
+template <class C>
+struct RecStage {
+  static constexpr int N = C::Fp::N;
+  static constexpr int Q = (2 * N + 1 + 3) / 4;            // quads covering x, y, flag
+  static constexpr int WAVE_WORDS = Q * 64 * 4;
+  static_assert(4 * Q <= Rec<C>::WORDS && (Rec<C>::WORDS % 4) == 0, "records are whole 16-byte quads");
+
+  // The instruction's immediate offset moves the global source AND the LDS destination
+  // (tools/microbench/glds_offset.hip), so one address register pair serves all quads: quad q is
+  // requested at offset 16q with the LDS base pulled back by the same 16q.
+  static __device__ __forceinline__ void issue(const uint32_t* recs, uint32_t idx, uint32_t* stage) {
+    const uint32_t* src = recs + (size_t)idx * Rec<C>::WORDS;
+    issue_quads(src, stage, std::make_integer_sequence<int, Q>());
+  }
+  template <int... Qs>
+  static __device__ __forceinline__ void issue_quads(const uint32_t* src, uint32_t* stage,
+                                                     std::integer_sequence<int, Qs...>) {
+    (__builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) uint32_t*)(stage + Qs * (256 - 4)), 16,
+                                      16 * Qs, 0),
+     ...);
+  }
+  // call after `s_waitcnt vmcnt(0)`; returns the flag word
+  static __device__ __forceinline__ uint32_t read(const uint32_t* stage, uint32_t lane, Fe<typename C::Fp>& x,
+                                                  Fe<typename C::Fp>& y) {
+    uint32_t w[4 * Q];
 #pragma unroll
-  for (int j = 0; j < W::NWIN; ++j) {
-    const int bit = j * WB, k = bit >> 5, sh = bit & 31;
-    const uint64_t two = ((uint64_t)w[k + 1] << 32) | w[k];
-    uint32_t d = ((uint32_t)(two >> sh) & ((1u << WB) - 1)) + carry;
-    uint32_t neg = 0;
-    if (d > (1u << (WB - 1))) { d = (1u << WB) - d; neg = 1; carry = 1; } else { carry = 0; }
-    const bool skip = (d == 0) || pt_inf;           // zero digit / infinity point contribute nothing
-    keys[(size_t)j * n + i] = skip ? W::SKIP : (typename W::Key)(d - 1);
-    vals[(size_t)j * n + i] = ((uint32_t)j * srs_n + i) | (neg << 31);
+    for (int q = 0; q < Q; ++q) {
+      const uint4 t = *reinterpret_cast<const uint4*>(stage + q * 256 + lane * 4);
+      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) { x.l[j] = w[j]; y.l[j] = w[N + j]; }
+    return w[Rec<C>::FLAG];
   }
-}
+};
 
-// bstart[k] = first sorted entry with key >= k, k = 0..NB  (bstart[NB] = #real entries);
-// lkey[k] = 255 - min(len_k, 255) (ascending sort => longest buckets first), lval[k] = k
-template <int WB>
-__global__ void msm_bounds_kernel(const typename Win<WB>::Key* keys, uint32_t m, uint32_t* bstart) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > Win<WB>::NB) return;
-  uint32_t lo = 0, hi = m;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (keys[mid] < k) lo = mid + 1; else hi = mid;
-  }
-  bstart[k] = lo;
-}
-template <int WB>
-__global__ void msm_lenkey_kernel(const uint32_t* bstart, uint8_t* lkey, uint32_t* lval) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= Win<WB>::NB) return;
-  const uint32_t len = bstart[k + 1] - bstart[k];
-  lkey[k] = (uint8_t)(255u - min(len, 255u));
-  lval[k] = k;
-}
-// ns[r] = slices of the r-th bucket in length order; ns[NB] = 0 (so the scan yields the total)
-template <int WB>
-__global__ void msm_ns_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t* ns) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > Win<WB>::NB) return;
-  if (r == Win<WB>::NB) { ns[r] = 0; return; }
-  const uint32_t k = order[r];
-  ns[r] = (bstart[k + 1] - bstart[k] + Win<WB>::SEG - 1) / Win<WB>::SEG;
-}
-
-#ifdef KZG_ACC_TWO_WAVES
-#define KZG_ACC_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
-#else
-#define KZG_ACC_ATTR
-#endif
+// Persistent kernel: the grid is a fixed number of waves per SIMD (msm_enqueue), each wave draws
+// chunks of 64 consecutive slices (one per lane; equal lengths, longest first) from a counter until
+// none are left.  Capping its share of every SIMD is what lets the next polynomial's prep kernels
+// and the previous one's reduce stage run beside it: a grid of one workgroup per 128 slices keeps
+// every wave slot refilled for 2 ms and starves them (measured: the sort made no progress).
+// Inner loop, software-pipelined one entry deep over two LDS stages per wave: while entry e is
+// added, the record of entry e+1 travels to the other stage and the table index of entry e+2 to a
+// register.
 template <class C, int WB>
-__global__ __launch_bounds__(128) KZG_ACC_ATTR void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
+__global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
                                                              const uint32_t* bstart, const uint32_t* order,
-                                                             const uint32_t* slice_off, uint32_t* partials) {
+                                                             const uint32_t* slice_off, uint32_t* partials,
+                                                             uint32_t* buckets, uint32_t* chunk_counter) {
   using F = typename C::Fp;
   using Fd = Field<F>;
+  using St = RecStage<C>;
   constexpr uint32_t NB = Win<WB>::NB;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= slice_off[NB]) return;
-  // rank of the bucket of slice t: largest r with slice_off[r] <= t
-  uint32_t lo = 0, hi = NB;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (slice_off[mid] <= t) lo = mid; else hi = mid;
-  }
-  const uint32_t r = lo;
-  const uint32_t k = order[r];
-  const uint32_t s = t - slice_off[r];
-  const uint32_t ns = slice_off[r + 1] - slice_off[r];
-  const uint32_t b0 = bstart[k];
-  const uint32_t len = bstart[k + 1] - b0;
-  const uint32_t e0 = b0 + (uint32_t)(((uint64_t)s * len) / ns);
-  const uint32_t e1 = b0 + (uint32_t)(((uint64_t)(s + 1) * len) / ns);
-  XYZZ<C> acc = Ec<C>::infinity();
-  bool finite = false;                       // accumulator is the point at infinity
-  for (uint32_t e = e0; e < e1; ++e) {
-    const uint32_t v = vals[e];
-    Fe<F> x, y;
-    load_rec<C>(recs, v & 0x7fffffffu, x, y);           // table coordinates are canonical
-    y = Fd::cneg_canonical(y, v >> 31);
-    if (!finite) {
-      acc.x = x; acc.y = y; acc.zz = Fd::one(); acc.zzz = Fd::one();
-      finite = true;
-    } else {
-      acc = Ec<C>::madd_finite(acc, x, y, finite);
+  __shared__ __attribute__((aligned(16))) uint32_t stage_all[2 * 2 * St::WAVE_WORDS];   // [wave][stage]
+  const uint32_t total = slice_off[NB];
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t* stage = stage_all + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * St::WAVE_WORDS);
+  for (;;) {
+    uint32_t chunk = 0;
+    if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
+    chunk = __builtin_amdgcn_readfirstlane(chunk);
+    if ((uint64_t)chunk * 64 >= total) break;          // every wave reaches this: the counter only grows
+    const uint32_t t = chunk * 64 + lane;
+    if (t >= total) continue;
+    // rank of the bucket of slice t: largest r with slice_off[r] <= t
+    uint32_t lo = 0, hi = NB;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (slice_off[mid] <= t) lo = mid; else hi = mid;
     }
+    const uint32_t r = lo;
+    const uint32_t k = order[r];
+    const uint32_t s = t - slice_off[r];
+    const uint32_t ns = slice_off[r + 1] - slice_off[r];
+    const uint32_t b0 = bstart[k];
+    const uint32_t len = bstart[k + 1] - b0;
+    uint32_t e = b0 + (uint32_t)(((uint64_t)s * len) / ns);
+    const uint32_t e1 = b0 + (uint32_t)(((uint64_t)(s + 1) * len) / ns);
+    // a bucket that is a single slice (the common case) is final; the others go through finalize.
+    // One register carries the destination through the loop: bit 31 = "bucket k", else partial t.
+    const uint32_t dst = ns == 1 ? (k | 0x80000000u) : t;
+    XYZZ<C> acc = Ec<C>::infinity();
+    bool finite = false;                       // accumulator is the point at infinity
+    uint32_t v_cur = 0, v_next = 0;
+    uint32_t it = 0;                            // the same for every lane still in the loop
+    if (e < e1) {
+      v_cur = vals[e];
+      if (e + 1 < e1) v_next = vals[e + 1];
+      St::issue(recs, v_cur & 0x7fffffffu, stage);       // stage 0; the previous chunk's reads have completed
+    }
+    while (e < e1) {
+      // record e is in stage it & 1, v_next in its register; every earlier LDS read has returned
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const uint32_t* cur = stage + (it & 1u) * St::WAVE_WORDS;
+      const uint32_t v = v_cur;
+      ++e;
+      ++it;
+      if (e < e1) {
+        v_cur = v_next;
+        St::issue(recs, v_cur & 0x7fffffffu, stage + (it & 1u) * St::WAVE_WORDS);
+        if (e + 1 < e1) v_next = vals[e + 1];
+      }
+      Fe<F> x, y;
+      const uint32_t flag = St::read(cur, lane, x, y);    // table coordinates are canonical
+      if (flag & 1u) continue;                            // key point at infinity contributes nothing
+      y = Fd::cneg_canonical(y, v >> 31);
+      if (!finite) {
+        acc.x = x; acc.y = y; acc.zz = Fd::one(); acc.zzz = Fd::one();
+        finite = true;
+      } else {
+        acc = Ec<C>::madd_finite(acc, x, y, finite);
+      }
+    }
+    if (!finite) acc = Ec<C>::infinity();
+    store_xyzz<C>((dst >> 31) ? buckets : partials, dst & 0x7fffffffu, acc);
   }
-  if (!finite) acc = Ec<C>::infinity();
-  store_xyzz<C>(partials, t, acc);
 }
+
+// The reduce-stage kernels run beside the persistent accumulate kernel, which holds 2 waves x 168
+// VGPRs of every SIMD: 176 VGPRs are left of the 512, i.e. the 168 of a 3-waves-per-SIMD budget.
+#define KZG_SIDE_VGPRS __attribute__((amdgpu_waves_per_eu(3, 3)))
 
 // Skewed scalars (many equal or small coefficients) put thousands of slices into a few buckets.
 // Buckets come in length order, so those are the first ranks: the first HEAVY_RANKS ranks whose
@@ -359,10 +397,11 @@ constexpr uint32_t HEAVY_RANKS = 256;
 constexpr uint32_t HEAVY_NS = 64;
 
 template <class C, int WB>
-__global__ __launch_bounds__(256) void msm_finalize_heavy_kernel(const uint32_t* partials, const uint32_t* order,
+__global__ __launch_bounds__(256) KZG_SIDE_VGPRS void msm_finalize_heavy_kernel(const uint32_t* partials, const uint32_t* order,
                                                                  const uint32_t* slice_off, uint32_t* buckets) {
+  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int N = C::Fp::N;
-  __shared__ uint32_t xch[3 * 4 * N];
+  __shared__ __attribute__((aligned(16))) uint32_t xch[3 * 4 * N];
   const uint32_t r = blockIdx.x;
   const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
   if (p1 - p0 <= HEAVY_NS) return;                 // whole block exits together
@@ -379,22 +418,30 @@ __global__ __launch_bounds__(256) void msm_finalize_heavy_kernel(const uint32_t*
   }
 }
 
-// FIN lanes per bucket (in length order) fold that bucket's slice partials
+// FIN lanes per bucket (in length order) fold the slice partials of the buckets that have more than
+// one slice, and empty buckets are set to infinity.  Single-slice buckets were written by the
+// accumulate kernel itself.  Slice counts do not increase with the rank, so a wave whose first and
+// last ranks both have exactly one slice has nothing to do - with uniform scalars, nearly all.
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_finalize_kernel(const uint32_t* partials, const uint32_t* order,
+__global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_finalize_kernel(const uint32_t* partials, const uint32_t* order,
                                                            const uint32_t* slice_off, uint32_t* buckets) {
+  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr uint32_t FIN = Win<WB>::FIN, NB = Win<WB>::NB;
+  static_assert(NB % (64 / FIN) == 0, "a wave covers whole ranks inside the bucket range");
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = gt / FIN, g = gt % FIN;
+  if (r >= NB) return;                               // whole waves (NB*FIN is a multiple of 64)
+  const uint32_t r_first = (gt & ~63u) / FIN, r_last = (gt | 63u) / FIN;
+  if (slice_off[r_first + 1] - slice_off[r_first] == 1 && slice_off[r_last + 1] - slice_off[r_last] == 1) return;
+  const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
+  const uint32_t cnt = p1 - p0;
+  const bool mine = cnt != 1 && !(r < HEAVY_RANKS && cnt > HEAVY_NS);   // heavy buckets: the other kernel
   XYZZ<C> acc = Ec<C>::infinity();
-  const bool heavy = r < HEAVY_RANKS && r < NB && slice_off[r + 1] - slice_off[r] > HEAVY_NS;   // other kernel
-  if (r < NB && !heavy) {
-    const uint32_t p0 = slice_off[r], p1 = slice_off[r + 1];
+  if (mine)
     for (uint32_t p = p0 + g; p < p1; p += FIN) acc = Ec<C>::add(acc, load_xyzz<C>(partials, p));
-  }
 #pragma unroll
   for (int m = 1; m < (int)FIN; m <<= 1) acc = Ec<C>::add(acc, shfl_xor_xyzz<C>(acc, m));
-  if (r < NB && g == 0 && !heavy) store_xyzz<C>(buckets, order[r], acc);
+  if (g == 0 && mine) store_xyzz<C>(buckets, order[r], acc);
 }
 
 // Row and column sums of the bucket matrix (entry v = hi*2^LO + lo is buckets[v-1]; v = 0 is
@@ -406,8 +453,9 @@ constexpr uint32_t RC_CH = 8;      // serial depth of step 1 (latency: the stage
 constexpr uint32_t RC_L2 = 16;
 
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
+__global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
                                                       uint32_t* rowpart) {
+  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
   constexpr uint32_t NCHR = (1u << LO) / RC_CH;            // chunks per row (interleaved)
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,8 +479,9 @@ __global__ __launch_bounds__(128) void msm_rc1_kernel(const uint32_t* buckets, u
 }
 
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_rc2_kernel(const uint32_t* colpart, const uint32_t* rowpart,
+__global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc2_kernel(const uint32_t* colpart, const uint32_t* rowpart,
                                                       uint32_t* colsum, uint32_t* rowsum) {
+  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
   constexpr uint32_t NCHC = (1u << HI) / RC_CH, NCHR = (1u << LO) / RC_CH;
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,10 +506,11 @@ __global__ __launch_bounds__(128) void msm_rc2_kernel(const uint32_t* colpart, c
 // with bit b of i set; block HI + b: same over colsum; last block: the top bucket (v = 2^(WB-1)).
 // Two waves per block: short serial part, 6 shuffle levels, one LDS hop.
 template <class C, int WB>
-__global__ __launch_bounds__(128) void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
+__global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
                                                          const uint32_t* buckets, uint32_t* out) {
+  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI, N = C::Fp::N;
-  __shared__ uint32_t xch[4 * N];
+  __shared__ __attribute__((aligned(16))) uint32_t xch[4 * N];
   const uint32_t blk = blockIdx.x, tid = threadIdx.x;
   XYZZ<C> acc = Ec<C>::infinity();
   if (blk < (uint32_t)(HI + LO)) {
@@ -639,8 +689,8 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 constexpr int NSLOT = 3;
 
 struct MsmSlot {
-  DevBuf keys_a, keys_b, vals_a, vals_b, bstart, lkey_a, lkey_b, lval_a, ns;       // prep
-  DevBuf order, slice_off, partials, buckets, rowsum, colsum, rowpart, colpart, tb;
+  DevBuf prep_ws, vals, bstart, order, slice_off, counter;                          // prep
+  DevBuf partials, buckets, rowsum, colsum, rowpart, colpart, tb;
   void* h_tb = nullptr;        // pinned host copy of the partial points
   hipEvent_t ev_in = nullptr;  // inputs ready on the context's stream
   hipEvent_t ev_p = nullptr;   // prep done
@@ -653,11 +703,10 @@ struct MsmSlot {
 };
 
 struct MsmWork {
-  DevBuf sort_tmp[NSLOT];
   MsmSlot slot[NSLOT];
-  hipStream_t stream_p = nullptr, stream_p2 = nullptr, stream_a = nullptr, stream_b = nullptr;
+  hipStream_t stream_p = nullptr, stream_a = nullptr, stream_b = nullptr;
   int next = 0;
-  int prev = -1;               // slot of the previously enqueued polynomial
+  uint32_t acc_blocks = 0;     // grid of the persistent accumulate kernel
 };
 
 static MsmWork* get_work(Ctx* c) {
@@ -667,17 +716,15 @@ static MsmWork* get_work(Ctx* c) {
 void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
-  for (auto& b : w->sort_tmp) hipFree(b.p);
   for (auto& sl : w->slot) {
-    for (DevBuf* b : {&sl.keys_a, &sl.keys_b, &sl.vals_a, &sl.vals_b, &sl.bstart, &sl.lkey_a, &sl.lkey_b, &sl.lval_a,
-                      &sl.ns, &sl.order, &sl.slice_off, &sl.partials, &sl.buckets, &sl.rowsum, &sl.colsum, &sl.rowpart,
-                      &sl.colpart, &sl.tb})
+    for (DevBuf* b : {&sl.prep_ws, &sl.vals, &sl.bstart, &sl.order, &sl.slice_off, &sl.counter, &sl.partials,
+                      &sl.buckets, &sl.rowsum, &sl.colsum, &sl.rowpart, &sl.colpart, &sl.tb})
       hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
     for (hipEvent_t e : {sl.ev_in, sl.ev_p, sl.ev_a, sl.ev_b})
       if (e) hipEventDestroy(e);
   }
-  for (hipStream_t st : {w->stream_p, w->stream_p2, w->stream_a, w->stream_b})
+  for (hipStream_t st : {w->stream_p, w->stream_a, w->stream_b})
     if (st) hipStreamDestroy(st);
   delete w;
   c->msm_work = nullptr;
@@ -686,22 +733,15 @@ void msm_free_work(Ctx* c) {
 template <class C, int WB>
 static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t n, MsmWork* w, int slot_idx) {
   using W = Win<WB>;
-  using Key = typename W::Key;
   constexpr size_t PT = 4 * C::Fp::N * 4;   // bytes of one XYZZ
   constexpr uint32_t NB = W::NB;
   MsmSlot& sl = w->slot[slot_idx];
   const uint32_t m = n * W::NWIN;
   const uint32_t max_slices = m / W::SEG + NB + 1;
   int rc;
-  if ((rc = ensure_buf(c, sl.keys_a, (size_t)m * sizeof(Key)))) return rc;
-  if ((rc = ensure_buf(c, sl.keys_b, (size_t)m * sizeof(Key)))) return rc;
-  if ((rc = ensure_buf(c, sl.vals_a, (size_t)m * 4))) return rc;
-  if ((rc = ensure_buf(c, sl.vals_b, (size_t)m * 4))) return rc;
+  if ((rc = ensure_buf(c, sl.prep_ws, msm_prep_workspace_bytes(n, WB)))) return rc;
+  if ((rc = ensure_buf(c, sl.vals, (size_t)m * 4))) return rc;
   if ((rc = ensure_buf(c, sl.bstart, (size_t)(NB + 2) * 4))) return rc;
-  if ((rc = ensure_buf(c, sl.lkey_a, NB))) return rc;
-  if ((rc = ensure_buf(c, sl.lkey_b, NB))) return rc;
-  if ((rc = ensure_buf(c, sl.lval_a, (size_t)NB * 4))) return rc;
-  if ((rc = ensure_buf(c, sl.ns, (size_t)(NB + 2) * 4))) return rc;
   if ((rc = ensure_buf(c, sl.order, (size_t)NB * 4))) return rc;
   if ((rc = ensure_buf(c, sl.slice_off, (size_t)(NB + 2) * 4))) return rc;
   if ((rc = ensure_buf(c, sl.partials, (size_t)max_slices * PT))) return rc;
@@ -711,87 +751,35 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.rowpart, (size_t)(NB / RC_CH) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.colpart, (size_t)(NB / RC_CH) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.tb, (size_t)MAX_NPART * PT))) return rc;
+  if ((rc = ensure_buf(c, sl.counter, 256))) return rc;
   if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
     if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   if (!w->stream_a) {
-    // prep and reduce kernels are short and memory- / latency-bound; the accumulate kernel fills the
-    // machine for milliseconds.  High priority for the former gets them dispatched as accumulate
-    // workgroups retire instead of starving behind its queue.  (A CU-masked partition was tried
-    // and was slower on this device; KZG_MSM_PRIO=0 turns priorities off.)
-    int lo_prio = 0, hi_prio = 0;
-    KZG_HIP(c, hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-    const char* e = getenv("KZG_MSM_PRIO");
-    const bool use_prio = !(e && atoi(e) == 0) && lo_prio != hi_prio;
-    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_a, hipStreamNonBlocking, use_prio ? lo_prio : 0));
-    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_p, hipStreamNonBlocking, use_prio ? hi_prio : 0));
-    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_p2, hipStreamNonBlocking, use_prio ? hi_prio : 0));
-    KZG_HIP(c, hipStreamCreateWithPriority(&w->stream_b, hipStreamNonBlocking, use_prio ? hi_prio : 0));
+    KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_a, hipStreamNonBlocking));
+    KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_p, hipStreamNonBlocking));
+    KZG_HIP(c, hipStreamCreateWithFlags(&w->stream_b, hipStreamNonBlocking));
+    // accumulate: 2 waves on every SIMD (4 workgroups of 2 waves per CU); KZG_ACC_WGS_PER_CU overrides
+    int cus = 0;
+    KZG_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const char* ew = getenv("KZG_ACC_WGS_PER_CU");
+    const int per_cu = ew && atoi(ew) > 0 ? atoi(ew) : 4;
+    w->acc_blocks = (uint32_t)std::max(cus, 1) * (uint32_t)per_cu;
   }
   sl.win_bits = WB;
 
-  auto* keys_a = static_cast<Key*>(sl.keys_a.p);
-  auto* keys_b = static_cast<Key*>(sl.keys_b.p);
-  auto* vals_a = static_cast<uint32_t*>(sl.vals_a.p);
-  auto* vals_b = static_cast<uint32_t*>(sl.vals_b.p);
-  auto* lkey_a = static_cast<uint8_t*>(sl.lkey_a.p);
-  auto* lkey_b = static_cast<uint8_t*>(sl.lkey_b.p);
-  auto* lval_a = static_cast<uint32_t*>(sl.lval_a.p);
-  auto* ns = static_cast<uint32_t*>(sl.ns.p);
+  auto* vals = static_cast<uint32_t*>(sl.vals.p);
   auto* bstart = static_cast<uint32_t*>(sl.bstart.p);
   auto* order = static_cast<uint32_t*>(sl.order.p);
   auto* slice_off = static_cast<uint32_t*>(sl.slice_off.p);
-  // KZG_MSM_STREAMS=2: prep shares the accumulate stream (only the reduce stage overlaps)
-  static const bool two_streams = [] { const char* e = getenv("KZG_MSM_STREAMS"); return e && atoi(e) == 2; }();
-  // KZG_MSM_PREP_STREAMS=2: consecutive polynomials prepare on alternating streams
-  static const bool two_prep = [] { const char* e = getenv("KZG_MSM_PREP_STREAMS"); return e && atoi(e) == 2; }();
-  hipStream_t sa = w->stream_a, sb = w->stream_b;
-  hipStream_t sp = two_streams ? sa : ((two_prep && (slot_idx & 1)) ? w->stream_p2 : w->stream_p);
-
-  constexpr unsigned SORT_BITS = WB <= 16 ? 16 : WB;
-  size_t t1 = 0, t2 = 0, t3 = 0;
-  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t1, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sp));
-  KZG_HIP(c, rocprim::radix_sort_pairs(nullptr, t2, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sp));
-  KZG_HIP(c, rocprim::exclusive_scan(nullptr, t3, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sp));
-  const size_t tmp_bytes = std::max(std::max(t1, t2), std::max(t3, (size_t)16));
-  DevBuf& tmp = w->sort_tmp[slot_idx];
-  if ((rc = ensure_buf(c, tmp, tmp_bytes))) return rc;
-
-  // Optional schedule  A(p) | prep(p+1) || reduce(p) | A(p+1)  (KZG_MSM_SERIAL=1): keeps the
-  // accumulate kernel alone on the machine.  Measured slower (287 vs 309 commits/s) than letting
-  // the three stages run freely, so it is off by default.
-  static const bool serial = [] { const char* e = getenv("KZG_MSM_SERIAL"); return e && atoi(e) == 1; }();
-  if (serial && w->prev >= 0 && w->prev != slot_idx) {
-    KZG_HIP(c, hipStreamWaitEvent(sp, w->slot[w->prev].ev_a, 0));   // prep(p+1) after accumulate(p)
-    KZG_HIP(c, hipStreamWaitEvent(sa, w->slot[w->prev].ev_b, 0));   // accumulate(p+1) after reduce(p)
-  }
-  w->prev = slot_idx;
+  hipStream_t sp = w->stream_p, sa = w->stream_a, sb = w->stream_b;
 
   // ---- stage P: prep
   KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));
   KZG_HIP(c, hipStreamWaitEvent(sp, sl.ev_in, 0));
-  {
-    ProfScope ps(c, "msm_digits", sp);
-    hipLaunchKernelGGL(msm_digits_kernel<WB>, dim3((n + 255) / 256), dim3(256), 0, sp, d_scalars, s->recs,
-                       (uint32_t)C::REC_WORDS, (uint32_t)Rec<C>::FLAG, n, (uint32_t)s->n, keys_a, vals_a);
-  }
-  KZG_HIP(c, hipGetLastError());
-  {
-    ProfScope ps(c, "msm_sort", sp);
-    size_t tb = tmp_bytes;
-    KZG_HIP(c, rocprim::radix_sort_pairs(tmp.p, tb, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0, SORT_BITS, sp));
-  }
-  {
-    ProfScope ps(c, "msm_bounds", sp);
-    hipLaunchKernelGGL(msm_bounds_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sp, keys_b, m, bstart);
-    hipLaunchKernelGGL(msm_lenkey_kernel<WB>, dim3((NB + 255) / 256), dim3(256), 0, sp, bstart, lkey_a, lval_a);
-    size_t tb = tmp_bytes;
-    KZG_HIP(c, rocprim::radix_sort_pairs(tmp.p, tb, lkey_a, lkey_b, lval_a, order, (size_t)NB, 0, 8, sp));
-    hipLaunchKernelGGL(msm_ns_kernel<WB>, dim3((NB + 1 + 255) / 256), dim3(256), 0, sp, bstart, order, ns);
-    tb = tmp_bytes;
-    KZG_HIP(c, rocprim::exclusive_scan(tmp.p, tb, ns, slice_off, 0u, (size_t)NB + 1, rocprim::plus<uint32_t>(), sp));
-  }
-  KZG_HIP(c, hipGetLastError());
+  if ((rc = msm_prep_enqueue(c, sp, WB, d_scalars, n, (uint32_t)s->n, W::SEG, sl.prep_ws.p, vals, bstart, order,
+                             slice_off, static_cast<uint32_t*>(sl.counter.p))))
+    return rc;
   KZG_HIP(c, hipEventRecord(sl.ev_p, sp));
   KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
 
@@ -799,8 +787,10 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   KZG_HIP(c, hipStreamWaitEvent(sa, sl.ev_p, 0));
   {
     ProfScope ps(c, "msm_accumulate", sa);
-    hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3((max_slices + 127) / 128), dim3(128), 0, sa, s->recs,
-                       vals_b, bstart, order, slice_off, static_cast<uint32_t*>(sl.partials.p));
+    hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3(std::min(w->acc_blocks, (max_slices + 127) / 128)),
+                       dim3(128), 0, sa, s->recs, vals, bstart, order, slice_off,
+                       static_cast<uint32_t*>(sl.partials.p), static_cast<uint32_t*>(sl.buckets.p),
+                       static_cast<uint32_t*>(sl.counter.p));
   }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipEventRecord(sl.ev_a, sa));

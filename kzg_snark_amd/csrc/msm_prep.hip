@@ -1,0 +1,432 @@
+// msm_prep.hip -- stage P of the commit pipeline: scalars -> bucket-sorted table indices.
+//
+// Replaces, for the MSM of msm.hip, what the reference does implicitly by walking the
+// coefficient list (kzg.py:112-116): every scalar is cut into W signed c-bit digits (zero digits
+// are dropped: the zero skip of kzg.py:113-114) and the (bucket, table index) entries are grouped
+// by bucket.  It is an MSD counting sort in two partition steps, written for running BESIDE the
+// persistent accumulate kernel of the previous polynomial: 256-thread workgroups, < 64 VGPRs,
+// <= 4 KiB of LDS and raised wave priority, so that its waves are placed in the registers the
+// accumulate kernel leaves free and win instruction issue when they have something to do (a
+// library radix sort with 1024-thread workgroups was measured to make no progress there).
+//
+//   partition 1   (one segment: all scalars, chunks of CH1 scalars)
+//     count1      digits of a chunk -> LDS histogram over NBIN bins (high bucket bits)
+//     row_scan    per bin: exclusive prefix over chunks;  bins: bin starts, chunk list for step 2
+//     scatter1    digits again -> 8-byte entries (low bucket bits | table index, sign) into the bin
+//   partition 2   (one segment per bin, chunks of CH2 entries; a skewed bin gets many chunks)
+//     count2      LDS histogram over the BPB buckets of the bin
+//     scan2       per bin: prefix over its chunks and over buckets -> bstart[] (bucket bounds)
+//     scatter2    table indices to their bucket
+//   order         buckets by length class (255 - min(len, 255): longest first), the same
+//                 count / row_scan / scatter scheme with 256 classes; slices of <= SEG entries
+//                 per bucket and their exclusive scan (slice_off); arms the work counter.
+//
+// Entries of one bucket land in no fixed order (LDS atomics hand out the ranks).  The group law
+// in ec.h is exact for every case, so the bucket sum - and the affine result - does not depend on it.
+#include <cstring>
+#include <string.h>
+#include <algorithm>
+#include "internal.h"
+#include "msm_prep.h"
+#include <rocprim/rocprim.hpp>
+
+namespace kzg {
+namespace {
+
+template <int WB>
+struct PW {
+  static constexpr int NWIN = (256 + WB - 1) / WB;
+  static constexpr uint32_t NB = 1u << (WB - 1);
+  static constexpr int LOB = WB >= 20 ? 10 : 9;           // low bucket bits: buckets per bin
+  static constexpr uint32_t BPB = 1u << LOB;
+  static constexpr uint32_t NBIN = NB >> LOB;             // 512 (c = 20) / 64 (c = 16)
+};
+constexpr uint32_t TPB = 256;     // threads per workgroup, every kernel here
+constexpr uint32_t CH1 = 1024;    // scalars per partition-1 chunk
+constexpr uint32_t CH2 = 8192;    // entries per partition-2 chunk
+constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
+constexpr uint32_t NCLS = 256;    // length classes
+
+__device__ __forceinline__ void side_priority() { __builtin_amdgcn_s_setprio(3); }
+
+// scalar i (8 little-endian words, < 2^255) -> signed digits; f(window, bucket = |d|-1, negative)
+// for every non-zero digit.  The top digit never wraps (msm.hip, Win).
+template <int WB, class Fn>
+__device__ __forceinline__ void for_each_digit(const uint32_t* scalars, uint32_t i, Fn&& f) {
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + (size_t)i * 8);
+  const uint4 lo4 = sp[0], hi4 = sp[1];
+  const uint32_t w[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
+  uint32_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < PW<WB>::NWIN; ++j) {
+    const int bit = j * WB, k = bit >> 5, sh = bit & 31;
+    const uint64_t two = ((uint64_t)w[k + 1] << 32) | w[k];
+    uint32_t d = ((uint32_t)(two >> sh) & ((1u << WB) - 1)) + carry;
+    uint32_t neg = 0;
+    if (d > (1u << (WB - 1))) { d = (1u << WB) - d; neg = 1; carry = 1; } else { carry = 0; }
+    if (d) f((uint32_t)j, d - 1, neg);
+  }
+}
+
+// inclusive scan of one value per thread over the 256 threads of the workgroup; `sh` has TPB words
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* sh) {
+  const uint32_t tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t off = 1; off < TPB; off <<= 1) {
+    const uint32_t t = tid >= off ? sh[tid - off] : 0u;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  return sh[tid];
+}
+
+// ---- partition 1 ------------------------------------------------------------------
+
+// hist1[bin][chunk] = entries of the chunk that fall into the bin
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_count1_kernel(const uint32_t* scalars, uint32_t n, uint32_t nchunk,
+                                                          uint32_t* hist1) {
+  using P = PW<WB>;
+  side_priority();
+  __shared__ uint32_t hist[P::NBIN];
+  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) hist[b] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * CH1;
+  for (uint32_t it = 0; it < CH1 / TPB; ++it) {
+    const uint32_t i = base + it * TPB + threadIdx.x;
+    if (i < n) for_each_digit<WB>(scalars, i, [&](uint32_t, uint32_t key, uint32_t) { atomicAdd(&hist[key >> P::LOB], 1u); });
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) hist1[(size_t)b * nchunk + blockIdx.x] = hist[b];
+}
+
+// one workgroup per row: exclusive prefix over the `len` entries of the row (in place), row total
+__global__ __launch_bounds__(TPB) void prep_row_scan_kernel(uint32_t* hist, uint32_t len, uint32_t* row_total) {
+  side_priority();
+  __shared__ uint32_t sh[TPB];
+  uint32_t* row = hist + (size_t)blockIdx.x * len;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < len; base += TPB) {
+    const uint32_t idx = base + threadIdx.x;
+    const uint32_t v = idx < len ? row[idx] : 0u;
+    const uint32_t incl = block_inclusive_scan(v, sh);
+    if (idx < len) row[idx] = carry + incl - v;
+    carry += sh[TPB - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+// one workgroup: bin starts (exclusive scan of the bin totals), the partition-2 chunk list
+// (chunk_base[s] .. chunk_base[s+1]: chunks of bin s; seg_of_chunk[g] = s), bstart[NB] = #entries
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_bins_kernel(const uint32_t* bin_total, uint32_t* bin_start,
+                                                        uint32_t* chunk_base, uint32_t* seg_of_chunk,
+                                                        uint32_t* nchunk2, uint32_t* bstart_top) {
+  using P = PW<WB>;
+  side_priority();
+  __shared__ uint32_t sh[TPB];
+  uint32_t size_carry = 0, chunk_carry = 0;
+  for (uint32_t base = 0; base < P::NBIN; base += TPB) {
+    const uint32_t s = base + threadIdx.x;
+    const uint32_t size = s < P::NBIN ? bin_total[s] : 0u;
+    const uint32_t nc = (size + CH2 - 1) / CH2;
+    const uint32_t size_incl = block_inclusive_scan(size, sh);
+    const uint32_t size_tot = sh[TPB - 1];
+    __syncthreads();
+    const uint32_t nc_incl = block_inclusive_scan(nc, sh);
+    const uint32_t nc_tot = sh[TPB - 1];
+    __syncthreads();
+    if (s < P::NBIN) {
+      bin_start[s] = size_carry + size_incl - size;
+      const uint32_t c0 = chunk_carry + nc_incl - nc;
+      chunk_base[s] = c0;
+      for (uint32_t q = 0; q < nc; ++q) seg_of_chunk[c0 + q] = s;
+    }
+    size_carry += size_tot;
+    chunk_carry += nc_tot;
+  }
+  if (threadIdx.x == 0) {
+    bin_start[P::NBIN] = size_carry;
+    chunk_base[P::NBIN] = chunk_carry;
+    *nchunk2 = chunk_carry;
+    *bstart_top = size_carry;
+  }
+}
+
+// entry = low bucket bits << 32 | sign << 31 | table index (window * srs_n + i)
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scalars, uint32_t n, uint32_t srs_n,
+                                                            uint32_t nchunk, const uint32_t* hist1,
+                                                            const uint32_t* bin_start, uint64_t* ent) {
+  using P = PW<WB>;
+  side_priority();
+  __shared__ uint32_t cur[P::NBIN];
+  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + blockIdx.x];
+  __syncthreads();
+  const uint32_t base = blockIdx.x * CH1;
+  for (uint32_t it = 0; it < CH1 / TPB; ++it) {
+    const uint32_t i = base + it * TPB + threadIdx.x;
+    if (i < n)
+      for_each_digit<WB>(scalars, i, [&](uint32_t j, uint32_t key, uint32_t neg) {
+        const uint32_t pos = atomicAdd(&cur[key >> P::LOB], 1u);
+        ent[pos] = ((uint64_t)(key & (P::BPB - 1)) << 32) | (uint64_t)((j * srs_n + i) | (neg << 31));
+      });
+  }
+}
+
+// ---- partition 2 ------------------------------------------------------------------
+
+struct Chunk2 {
+  uint32_t seg, e0, e1;
+};
+__device__ __forceinline__ Chunk2 chunk2_of(uint32_t g, const uint32_t* bin_start, const uint32_t* chunk_base,
+                                            const uint32_t* seg_of_chunk) {
+  Chunk2 c;
+  c.seg = seg_of_chunk[g];
+  const uint32_t lc = g - chunk_base[c.seg];
+  c.e0 = bin_start[c.seg] + lc * CH2;
+  c.e1 = min(c.e0 + CH2, bin_start[c.seg + 1]);
+  return c;
+}
+
+// hist2[chunk][bucket-in-bin]
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_count2_kernel(const uint64_t* ent, const uint32_t* bin_start,
+                                                          const uint32_t* chunk_base, const uint32_t* seg_of_chunk,
+                                                          const uint32_t* nchunk2, uint32_t* hist2) {
+  using P = PW<WB>;
+  side_priority();
+  const uint32_t g = blockIdx.x;
+  if (g >= *nchunk2) return;
+  __shared__ uint32_t hist[P::BPB];
+  for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB) hist[b] = 0;
+  __syncthreads();
+  const Chunk2 c = chunk2_of(g, bin_start, chunk_base, seg_of_chunk);
+  for (uint32_t e = c.e0 + threadIdx.x; e < c.e1; e += TPB) atomicAdd(&hist[(uint32_t)(ent[e] >> 32)], 1u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB) hist2[(size_t)g * P::BPB + b] = hist[b];
+}
+
+// one workgroup per bin: hist2[chunk][b] -> entries of bucket b in earlier chunks of the bin;
+// bstart[bin * BPB + b] = first sorted entry of the bucket
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_scan2_kernel(uint32_t* hist2, const uint32_t* bin_start,
+                                                         const uint32_t* chunk_base, uint32_t* bstart) {
+  using P = PW<WB>;
+  constexpr uint32_t PER = P::BPB / TPB;
+  side_priority();
+  __shared__ uint32_t tot[P::BPB];
+  __shared__ uint32_t sh[TPB];
+  const uint32_t s = blockIdx.x;
+  const uint32_t c0 = chunk_base[s], c1 = chunk_base[s + 1];
+  for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB) {
+    uint32_t run = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+      const uint32_t v = hist2[(size_t)c * P::BPB + b];
+      hist2[(size_t)c * P::BPB + b] = run;
+      run += v;
+    }
+    tot[b] = run;
+  }
+  __syncthreads();
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) mine += tot[threadIdx.x * PER + q];
+  const uint32_t incl = block_inclusive_scan(mine, sh);
+  uint32_t run = bin_start[s] + incl - mine;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) {
+    bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = run;
+    run += tot[threadIdx.x * PER + q];
+  }
+}
+
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_scatter2_kernel(const uint64_t* ent, const uint32_t* bin_start,
+                                                            const uint32_t* chunk_base, const uint32_t* seg_of_chunk,
+                                                            const uint32_t* nchunk2, const uint32_t* hist2,
+                                                            const uint32_t* bstart, uint32_t* vals) {
+  using P = PW<WB>;
+  side_priority();
+  const uint32_t g = blockIdx.x;
+  if (g >= *nchunk2) return;
+  __shared__ uint32_t cur[P::BPB];
+  const Chunk2 c = chunk2_of(g, bin_start, chunk_base, seg_of_chunk);
+  for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB)
+    cur[b] = bstart[(size_t)c.seg * P::BPB + b] + hist2[(size_t)g * P::BPB + b];
+  __syncthreads();
+  for (uint32_t e = c.e0 + threadIdx.x; e < c.e1; e += TPB) {
+    const uint64_t v = ent[e];
+    const uint32_t pos = atomicAdd(&cur[(uint32_t)(v >> 32)], 1u);
+    vals[pos] = (uint32_t)v;
+  }
+}
+
+// ---- buckets in length order ----------------------------------------------------------
+
+__device__ __forceinline__ uint32_t length_class(uint32_t len) { return 255u - min(len, 255u); }
+
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_lcount_kernel(const uint32_t* bstart, uint32_t nchunk, uint32_t* histl) {
+  using P = PW<WB>;
+  side_priority();
+  __shared__ uint32_t hist[NCLS];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * CHL;
+  for (uint32_t it = 0; it < CHL / TPB; ++it) {
+    const uint32_t k = base + it * TPB + threadIdx.x;
+    if (k < P::NB) atomicAdd(&hist[length_class(bstart[k + 1] - bstart[k])], 1u);
+  }
+  __syncthreads();
+  histl[(size_t)threadIdx.x * nchunk + blockIdx.x] = hist[threadIdx.x];
+}
+
+// one workgroup: class_start = exclusive scan of the NCLS (= TPB) class totals
+__global__ __launch_bounds__(TPB) void prep_classes_kernel(const uint32_t* class_total, uint32_t* class_start) {
+  side_priority();
+  __shared__ uint32_t sh[TPB];
+  const uint32_t v = class_total[threadIdx.x];
+  const uint32_t incl = block_inclusive_scan(v, sh);
+  class_start[threadIdx.x] = incl - v;
+}
+
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_lscatter_kernel(const uint32_t* bstart, uint32_t nchunk,
+                                                            const uint32_t* histl, const uint32_t* class_start,
+                                                            uint32_t* order) {
+  using P = PW<WB>;
+  side_priority();
+  __shared__ uint32_t cur[NCLS];
+  cur[threadIdx.x] = class_start[threadIdx.x] + histl[(size_t)threadIdx.x * nchunk + blockIdx.x];
+  __syncthreads();
+  const uint32_t base = blockIdx.x * CHL;
+  for (uint32_t it = 0; it < CHL / TPB; ++it) {
+    const uint32_t k = base + it * TPB + threadIdx.x;
+    if (k < P::NB) order[atomicAdd(&cur[length_class(bstart[k + 1] - bstart[k])], 1u)] = k;
+  }
+}
+
+// ns[r] = slices of the r-th bucket in length order; ns[NB] = 0 (so the scan yields the total);
+// also arms the accumulate kernel's work counter
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_ns_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t seg,
+                                                      uint32_t* ns, uint32_t* chunk_counter) {
+  side_priority();
+  const uint32_t r = blockIdx.x * TPB + threadIdx.x;
+  if (r > PW<WB>::NB) return;
+  if (r == PW<WB>::NB) { ns[r] = 0; *chunk_counter = 0; return; }
+  const uint32_t k = order[r];
+  ns[r] = (bstart[k + 1] - bstart[k] + seg - 1) / seg;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+template <int WB>
+struct Layout {
+  using P = PW<WB>;
+  uint32_t m, nchunk1, nchunk2_max, nchunkl;
+  size_t off_ent, off_hist1, off_bin_total, off_bin_start, off_chunk_base, off_seg_of_chunk, off_nchunk2, off_hist2,
+      off_histl, off_class_total, off_class_start, off_ns, off_scan_tmp, scan_tmp_bytes, total;
+  explicit Layout(uint32_t n) {
+    m = n * (uint32_t)P::NWIN;
+    nchunk1 = (n + CH1 - 1) / CH1;
+    nchunk2_max = m / CH2 + P::NBIN + 1;
+    nchunkl = (P::NB + CHL - 1) / CHL;
+    size_t t = 0;
+    auto take = [&](size_t bytes) { const size_t o = t; t += align256(bytes); return o; };
+    off_ent = take((size_t)m * 8);
+    off_hist1 = take((size_t)P::NBIN * nchunk1 * 4);
+    off_bin_total = take((size_t)P::NBIN * 4);
+    off_bin_start = take((size_t)(P::NBIN + 1) * 4);
+    off_chunk_base = take((size_t)(P::NBIN + 1) * 4);
+    off_seg_of_chunk = take((size_t)nchunk2_max * 4);
+    off_nchunk2 = take(4);
+    off_hist2 = take((size_t)nchunk2_max * P::BPB * 4);
+    off_histl = take((size_t)NCLS * nchunkl * 4);
+    off_class_total = take(NCLS * 4);
+    off_class_start = take(NCLS * 4);
+    off_ns = take((size_t)(P::NB + 2) * 4);
+    scan_tmp_bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P::NB + 1,
+                            rocprim::plus<uint32_t>(), nullptr);
+    scan_tmp_bytes = std::max(scan_tmp_bytes, (size_t)16);
+    off_scan_tmp = take(scan_tmp_bytes);
+    total = t;
+  }
+};
+
+template <int WB>
+int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n, uint32_t seg,
+                   void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
+                   uint32_t* chunk_counter) {
+  using P = PW<WB>;
+  const Layout<WB> L(n);
+  char* w = static_cast<char*>(ws);
+  auto* ent = reinterpret_cast<uint64_t*>(w + L.off_ent);
+  auto* hist1 = reinterpret_cast<uint32_t*>(w + L.off_hist1);
+  auto* bin_total = reinterpret_cast<uint32_t*>(w + L.off_bin_total);
+  auto* bin_start = reinterpret_cast<uint32_t*>(w + L.off_bin_start);
+  auto* chunk_base = reinterpret_cast<uint32_t*>(w + L.off_chunk_base);
+  auto* seg_of_chunk = reinterpret_cast<uint32_t*>(w + L.off_seg_of_chunk);
+  auto* nchunk2 = reinterpret_cast<uint32_t*>(w + L.off_nchunk2);
+  auto* hist2 = reinterpret_cast<uint32_t*>(w + L.off_hist2);
+  auto* histl = reinterpret_cast<uint32_t*>(w + L.off_histl);
+  auto* class_total = reinterpret_cast<uint32_t*>(w + L.off_class_total);
+  auto* class_start = reinterpret_cast<uint32_t*>(w + L.off_class_start);
+  auto* ns = reinterpret_cast<uint32_t*>(w + L.off_ns);
+  {
+    ProfScope ps(c, "msm_partition1", sp);
+    hipLaunchKernelGGL(prep_count1_kernel<WB>, dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, L.nchunk1, hist1);
+    hipLaunchKernelGGL(prep_row_scan_kernel, dim3(P::NBIN), dim3(TPB), 0, sp, hist1, L.nchunk1, bin_total);
+    hipLaunchKernelGGL(prep_bins_kernel<WB>, dim3(1), dim3(TPB), 0, sp, bin_total, bin_start, chunk_base, seg_of_chunk,
+                       nchunk2, bstart + P::NB);
+    hipLaunchKernelGGL(prep_scatter1_kernel<WB>, dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, srs_n, L.nchunk1,
+                       hist1, bin_start, ent);
+  }
+  KZG_HIP(c, hipGetLastError());
+  {
+    ProfScope ps(c, "msm_partition2", sp);
+    hipLaunchKernelGGL(prep_count2_kernel<WB>, dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
+                       seg_of_chunk, nchunk2, hist2);
+    hipLaunchKernelGGL(prep_scan2_kernel<WB>, dim3(P::NBIN), dim3(TPB), 0, sp, hist2, bin_start, chunk_base, bstart);
+    hipLaunchKernelGGL(prep_scatter2_kernel<WB>, dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
+                       seg_of_chunk, nchunk2, hist2, bstart, vals);
+  }
+  KZG_HIP(c, hipGetLastError());
+  {
+    ProfScope ps(c, "msm_order", sp);
+    hipLaunchKernelGGL(prep_lcount_kernel<WB>, dim3(L.nchunkl), dim3(TPB), 0, sp, bstart, L.nchunkl, histl);
+    hipLaunchKernelGGL(prep_row_scan_kernel, dim3(NCLS), dim3(TPB), 0, sp, histl, L.nchunkl, class_total);
+    hipLaunchKernelGGL(prep_classes_kernel, dim3(1), dim3(TPB), 0, sp, class_total, class_start);
+    hipLaunchKernelGGL(prep_lscatter_kernel<WB>, dim3(L.nchunkl), dim3(TPB), 0, sp, bstart, L.nchunkl, histl,
+                       class_start, order);
+    hipLaunchKernelGGL(prep_ns_kernel<WB>, dim3((P::NB + 1 + TPB - 1) / TPB), dim3(TPB), 0, sp, bstart, order, seg, ns,
+                       chunk_counter);
+    size_t tb = L.scan_tmp_bytes;
+    KZG_HIP(c, rocprim::exclusive_scan(w + L.off_scan_tmp, tb, ns, slice_off, 0u, (size_t)P::NB + 1,
+                                       rocprim::plus<uint32_t>(), sp));
+  }
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+}  // namespace
+
+size_t msm_prep_workspace_bytes(uint32_t n, int win_bits) {
+  return win_bits == 20 ? Layout<20>(n).total : Layout<16>(n).total;
+}
+
+int msm_prep_enqueue(Ctx* c, hipStream_t sp, int win_bits, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n,
+                     uint32_t seg, void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
+                     uint32_t* chunk_counter) {
+  return win_bits == 20
+             ? prep_enqueue_t<20>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off, chunk_counter)
+             : prep_enqueue_t<16>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off, chunk_counter);
+}
+
+}  // namespace kzg

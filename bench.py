@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--batch", type=int, default=4, help="polynomials per step (one commit call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the one-commit-at-a-time accumulate timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
                                                       "multi-rank path with all ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -171,7 +172,7 @@ def main():
     # The NTT half of the metric, timed alone (inside the pipelined loop above its kernels share the
     # GPU with the previous polynomial's bucket reduction, which inflates their event times).
     spans_main = {name: ctx.prof_read(name) for name in
-                  ("msm_digits", "msm_sort", "msm_bounds", "msm_accumulate", "msm_finalize", "msm_reduce")}
+                  ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
     ctx.prof_enable(True)
     ctx.prof_reset()
     ntt_iters = max(args.steps, 10)
@@ -179,6 +180,17 @@ def main():
         ctx.ntt_device(works[0].data_ptr(), log_n, w_words, bool(i & 1) ^ True, B)
     barrier()
     ntt_alone = ctx.prof_read("ntt_pass")
+    # The accumulate kernel alone: in the pipelined loop it deliberately shares every SIMD with the
+    # next polynomial's prep and the previous one's reduce stage, so its span there is the pipeline
+    # period.  One commit at a time (flush after each) gives the kernel's own duration.
+    ctx.prof_reset()
+    for p in range(0 if args.no_isolated else B):
+        xy1 = np.zeros((1, 2 * fp_limbs), dtype=np.uint64)
+        inf1 = np.zeros(1, dtype=np.uint8)
+        ctx.commit_device_async(srs, works[0].data_ptr() + p * n * 32, [n], n, xy1, inf1)
+        ctx.commit_flush()
+    barrier()
+    acc_alone = ctx.prof_read("msm_accumulate")
     ctx.prof_enable(False)
 
     spans = dict(spans_main)
@@ -223,6 +235,14 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_launch": msm_bytes,
                 "avg_launch_ms": acc_avg_s * 1e3,
+                "isolated": {   # same kernel with nothing else on the GPU (one commit at a time)
+                    "avg_launch_ms": acc_alone[0] / max(acc_alone[1], 1),
+                    "achieved": msm_bytes / (acc_alone[0] / max(acc_alone[1], 1) * 1e-3) / 1e9 if acc_alone[0] > 0 else None,
+                    "frac": msm_bytes / (acc_alone[0] / max(acc_alone[1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                    if acc_alone[0] > 0 else None,
+                },
+                "note": "in the timed loop the persistent accumulate kernel runs beside prep(p+1) and reduce(p-1); "
+                        "its span there is the pipeline period",
             },
             "roofline_ntt": {
                 "kernel": "ntt_pass_kernel (2 launches per transform)",

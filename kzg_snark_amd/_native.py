@@ -14,7 +14,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkzg_mi355x.so")
+# KZG_MI355X_LIB: load another build of the library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("KZG_MI355X_LIB") or os.path.join(_HERE, "lib", "libkzg_mi355x.so")
 
 KZG_CURVE_BN254 = 0
 KZG_CURVE_BLS12_381 = 1

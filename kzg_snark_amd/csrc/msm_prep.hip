@@ -42,12 +42,18 @@ struct PW {
   static constexpr uint32_t NBIN = NB >> LOB;             // 512 (c = 20) / 64 (c = 16)
 };
 constexpr uint32_t TPB = 256;     // threads per workgroup, every kernel here
-constexpr uint32_t CH1 = 1024;    // scalars per partition-1 chunk
+#ifndef KZG_PREP_PRIO
+#define KZG_PREP_PRIO 3
+#endif
+#ifndef KZG_PREP_CH1
+#define KZG_PREP_CH1 1024
+#endif
+constexpr uint32_t CH1 = KZG_PREP_CH1;    // scalars per partition-1 chunk
 constexpr uint32_t CH2 = 8192;    // entries per partition-2 chunk
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
 constexpr uint32_t NCLS = 256;    // length classes
 
-__device__ __forceinline__ void side_priority() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void side_priority() { __builtin_amdgcn_s_setprio(KZG_PREP_PRIO); }
 
 // scalar i (8 little-endian words, < 2^255) -> signed digits; f(window, bucket = |d|-1, negative)
 // for every non-zero digit.  The top digit never wraps (msm.hip, Win).

@@ -23,8 +23,8 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     m = re.search(r"(\w+_kernel)<?", name)
-    if "radix_sort" in name or "rocprim" in name:
-        return "rocprim_radix_sort"
+    if "rocprim" in name:
+        return "rocprim_scan"
     return m.group(1) if m else name[:48]
 
 

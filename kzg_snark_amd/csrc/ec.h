@@ -105,14 +105,24 @@ struct Ec {
   }
 
   // madd for an accumulator known to be finite; `finite` is cleared when the sum is infinity.
-  // The hot loop of the MSM: tracks infinity in a flag instead of testing ZZ every time.
+  // The hot loop of the MSM: tracks infinity in a flag instead of testing ZZ every time, and
+  // forms every difference lazily (Field::sub_carry: a - b + K*p, carried, never reduced).
+  // Value ranges, as multiples of p (limbs always normalised):
+  //   in:  X1 < 8, Y1, ZZ1, ZZZ1 < 2 (products), x2 < 1, y2 <= 1
+  //   Pp = U2 - X1 + 8p < 10     R = S2 - Y1 + 2p < 4      PP, PPP, Q, RR < 2 (products)
+  //   X3 = RR - (PPP + 2Q) + 6p < 8      Q - X3 + 8p < 10      Y3 = mul2(...) < 2
+  // Largest operand products: Pp^2 < 100 p^2, mul2: 4*10 + 2*2 = 44 p^2 -- below R*p for both
+  // base fields (R/p = 168 for BN254, 630 for BLS12-381).  Zero tests go through a product, which
+  // is weak-normal: Pp = 0 mod p  <=>  PP = 0 mod p (p prime), likewise R and RR.
+  // Consumers of the accumulator (add, dbl, to_affine) use X only as a mul/sqr operand.
   static KZG_HD P madd_finite(const P& a, const E& x2, const E& y2, bool& finite) {
     const E U2 = Fd::mul(x2, a.zz);
     const E S2 = Fd::mul(y2, a.zzz);
-    const E Pp = Fd::sub(U2, a.x);
-    const E R = Fd::sub(S2, a.y);
-    if (Fd::is_zero_weak(Pp)) {
-      if (Fd::is_zero_weak(R)) {
+    const E Pp = Fd::template sub_carry<8>(U2, a.x);
+    const E R = Fd::template sub_carry<2>(S2, a.y);
+    const E PP = Fd::sqr(Pp);
+    if (Fd::is_zero_weak(PP)) {
+      if (Fd::is_zero_weak(Fd::sqr(R))) {
         const P d = dbl_affine(x2, y2);
         finite = !is_inf(d);
         return d;
@@ -120,12 +130,11 @@ struct Ec {
       finite = false;
       return infinity();
     }
-    const E PP = Fd::sqr(Pp);
     const E PPP = Fd::mul(Pp, PP);
     const E Q = Fd::mul(a.x, PP);
     P r;
-    r.x = Fd::sub(Fd::sub(Fd::sqr(R), PPP), Fd::dbl(Q));
-    r.y = Fd::mul2(R, Fd::sub(Q, r.x), Fd::neg_weak(a.y), PPP);
+    r.x = Fd::template sub_carry<6>(Fd::sqr(R), Fd::add_twice_carry(PPP, Q));
+    r.y = Fd::mul2(R, Fd::template sub_carry<8>(Q, r.x), Fd::neg_weak(a.y), PPP);   // R*(Q - X3) - Y1*PPP
     r.zz = Fd::mul(a.zz, PP);
     r.zzz = Fd::mul(a.zzz, PPP);
     return r;

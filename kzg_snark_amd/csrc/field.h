@@ -311,6 +311,50 @@ struct Field {
     return r;
   }
 
+  // ---- lazy forms with normalised limbs (the MSM inner loop) --------------------------------
+  // mul / sqr / mul2 only need normalised limbs and a product of the operand VALUES below R*p
+  // (R/p > 160 for the two base fields), not weak-normal operands.  So between multiplications
+  // a difference is formed as a - b + K*p (K*p >= b, nothing else to decide) and carried, with
+  // no conditional subtraction and no signed borrow chain: value in [0, a + K*p), limbs < 2^L.
+  template <int K>
+  static KZG_HD const uint32_t* pkr() {
+    static_assert(K == 2 || K == 4 || K == 6 || K == 8, "no redistributed constant for this multiple of p");
+    if constexpr (K == 2) return F::P2R;
+    else if constexpr (K == 4) return F::P4R;
+    else if constexpr (K == 6) return F::P6R;
+    else return F::P8R;
+  }
+  // a - b + K*p for normalised a, b with b <= K*p.  Every lower limb of the redistributed K*p
+  // dominates a normalised limb; the top limb may wrap below zero on the way and is put right by
+  // the incoming carry (arithmetic mod 2^32, true value non-negative).
+  template <int K>
+  static KZG_HD E sub_carry(const E& a, const E& b) {
+    const uint32_t* kp = pkr<K>();
+    E r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint32_t t = a.l[j] + (kp[j] - b.l[j]) + c;
+      r.l[j] = t & MASK;
+      c = t >> L;
+    }
+    r.l[N - 1] = a.l[N - 1] + (kp[N - 1] - b.l[N - 1]) + c;
+    return r;
+  }
+  // a + b + b for normalised operands: value a + 2b, limbs normalised
+  static KZG_HD E add_twice_carry(const E& a, const E& b) {
+    E r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const uint32_t t = a.l[j] + 2 * b.l[j] + c;
+      r.l[j] = t & MASK;
+      c = t >> L;
+    }
+    r.l[N - 1] = a.l[N - 1] + 2 * b.l[N - 1] + c;
+    return r;
+  }
+
   static KZG_HD E dbl(const E& a) { return add(a, a); }
   static KZG_HD E neg(const E& a) { return sub(zero(), a); }
 

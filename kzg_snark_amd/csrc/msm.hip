@@ -676,7 +676,7 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
                        : srs_export_t<Bls12_381>(c, s, start, count, xy, inf);
 }
 
-// Commit pipeline: three stages on three internal streams, three polynomials in flight.
+// Commit pipeline: three stages on three internal streams, up to four polynomials in flight.
 //   P  prep        digits, two-step partition, bucket order, slices (memory-bound, msm_prep.hip)
 //   A  accumulate  the mixed-addition kernel                        (ALU-bound, persistent)
 //   B  reduce      finalize, row/column sums, bit planes, copy-out  (latency-bound)
@@ -686,7 +686,7 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 // waits for P to have consumed the scalars, so later work on the context's stream (the next NTT)
 // can neither race with prep nor queue behind accumulate.  Every buffer belongs to a slot; the
 // host finishes a polynomial (Horner + one inversion) when its slot is recycled or on flush.
-constexpr int NSLOT = 3;
+constexpr int NSLOT = 4;
 
 struct MsmSlot {
   DevBuf prep_ws, vals, bstart, order, slice_off, counter;                          // prep

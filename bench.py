@@ -129,15 +129,16 @@ def main():
     host = torch.randint(0, 1 << 62, (B, n, 4), generator=g, dtype=torch.int64)
     host[:, :, 3] >>= 3                                    # < 2^253 < r
     evals = host.to(dev)
-    # two work buffers: a step's coefficients stay untouched while its commits are in flight
-    works = [torch.empty_like(evals), torch.empty_like(evals)]
+    # two work buffers: a step's coefficients stay untouched while its commits are in flight.  A step
+    # transforms its buffer in place, so the "evaluations" of step i+2 are the coefficients of step i:
+    # an INTT is a bijection on Fr^n, the scalars stay uniform, and no copy sits in the timed region.
+    works = [evals.clone(), evals]
     lens = [n] * B
     fp_limbs = ctx.fp_limbs
     results = {}
 
     def step(i):
         work = works[i & 1]
-        work.copy_(evals)                                   # the INTT is in place; keep the input resident
         ctx.ntt_device(work.data_ptr(), log_n, w_words, True, B)
         out_xy = np.zeros((B, 2 * fp_limbs), dtype=np.uint64)
         out_inf = np.zeros(B, dtype=np.uint8)

@@ -377,3 +377,13 @@ def test_skewed_scalars_2_20(native, kzgs):
     xy, inf = ctx.commit(ck.srs, small.reshape(1, n, 4), [n], n)
     coeffs = [int(v) for v in small[:, 0]]
     assert tuple(native.limbs_to_ints(xy.reshape(2, 6))) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+    # one BIN of the two-step partition receives every entry, spread over all of its buckets (scalars
+    # below 2^10 fill the 1024 buckets of bin 0): that bin is cut into 2^20 / 8192 chunks, each with
+    # a histogram over many buckets; and the same shifted into the second window (multiples of 2^20)
+    for shift in (0, 20):
+        vals = rs.randint(0, 1 << 10, size=n).astype(np.uint64)
+        sc = np.zeros((n, 4), dtype=np.uint64)
+        sc[:, 0] = vals << np.uint64(shift)
+        xy, inf = ctx.commit(ck.srs, sc.reshape(1, n, 4), [n], n)
+        coeffs = [int(v) << shift for v in vals]
+        assert tuple(native.limbs_to_ints(xy.reshape(2, 6))) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)

@@ -123,7 +123,7 @@ int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const 
 int kzg_commit_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, const size_t* lens, size_t n_polys,
                       size_t stride, uint64_t* out_xy, uint8_t* out_inf);
 
-/* Pipelined form: returns after enqueueing; up to two polynomials stay in flight across calls.
+/* Pipelined form: returns after enqueueing; up to three polynomials stay in flight across calls.
  * The scalars of an in-flight polynomial must stay untouched and out_xy / out_inf stay valid
  * until kzg_commit_flush() returns (or until a later call on this context has recycled the
  * slot); results are written by the host thread inside those calls. */
@@ -177,8 +177,8 @@ int kzg_fr_vec_prefix_product(kzg_ctx* ctx, size_t n, const void* d_a, void* d_o
 int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4], uint64_t out[4]);
 
 /* ---- measurement hooks (bench.py) -----------------------------------------------------------
- * When enabled, the library brackets its kernels with HIP events on the context's stream.
- * Span names: "ntt_pass", "msm_digits", "msm_sort", "msm_bounds", "msm_accumulate",
+ * When enabled, the library brackets its kernels with HIP events on the stream each one runs on.
+ * Span names: "ntt_pass", "msm_partition1", "msm_partition2", "msm_order", "msm_accumulate",
  * "msm_finalize", "msm_reduce", "open_poly".  kzg_prof_read synchronises the stream and returns
  * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset. */
 int kzg_prof_enable(kzg_ctx* ctx, int on);

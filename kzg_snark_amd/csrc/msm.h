@@ -20,7 +20,7 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 void srs_free(Srs* s);
 
 // One MSM per polynomial; scalars device-resident, results to host memory (synchronises).
-// drain = false leaves up to three polynomials in flight; their outputs are written when their
+// drain = false leaves up to four polynomials in flight; their outputs are written when their
 // slot is recycled by a later call or by commit_flush().
 int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
                   size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain = true);

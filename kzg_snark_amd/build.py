@@ -16,7 +16,7 @@ LIB = os.path.join(LIBDIR, "libkzg_mi355x.so")
 SOURCES = ["api.hip", "ntt.hip", "msm.hip", "msm_prep.hip", "poly.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-Wno-pass-failed"]
 FLAGS += os.environ.get("KZG_EXTRA_HIPCC_FLAGS", "").split()
 
 

@@ -455,7 +455,7 @@ template <class C, int WB>
 __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
                                                       uint32_t* rowpart) {
   __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
-  constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
+  constexpr int LO = Win<WB>::LO;
   constexpr uint32_t NCHR = (1u << LO) / RC_CH;            // chunks per row (interleaved)
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= Win<WB>::NB / RC_CH) return;

@@ -85,9 +85,10 @@ int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[
  * all-to-all transposes.  Requires log_n > 12.
  *   columns: d_data is an [N1][n_cols] row-major matrix holding global columns col_base ..
  *            col_base+n_cols-1 of the N1 x N2 view; transformed in place down the columns and
- *            multiplied by the twist w^(row * global column).
+ *            multiplied by the twist w^(row * global column) -- and by n^-1 when inverse (the scale
+ *            of fft_ff.py:57-58 rides on the twist; the two halves are only meaningful as a pair).
  *   rows:    d_data is an [n_rows][N2] matrix (n_rows rows of the twisted matrix); transformed in
- *            place along the rows, natural order, and scaled (by n^-1 when inverse).
+ *            place along the rows, natural order.
  * n_cols / n_rows: powers of two. */
 int kzg_ntt_columns_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                            uint64_t n_cols, uint64_t col_base);

@@ -378,6 +378,27 @@ struct Field {
     for (int j = 0; j < N; ++j) r.l[j] = neg ? a.l[j] : t.l[j];
     return r;
   }
+  // [0, 2^(L*N)) with normalised limbs -> [0, p): the canonical value of a lazily accumulated sum
+  // (NTT butterflies: up to 49p) without a multiplication.  Quotient estimate from the top limb:
+  // q = floor(top * floor(2^52 / (ptop + 1)) / 2^52) with ptop = top limb of p never exceeds
+  // floor(x / p) and falls short of it by at most 1 (the estimate loses < 2^-13 + rounding), so
+  // x - q*p is in [0, 2p) and one conditional subtraction finishes.
+  static KZG_HD E reduce_wide(const E& a) {
+    constexpr uint64_t PTOP1 = (uint64_t)F::P[N - 1] + 1;
+    constexpr uint64_t M = (1ull << 52) / PTOP1;
+    static_assert(PTOP1 > (1ull << 20), "top limb of p too small for the 52-bit reciprocal");
+    const uint32_t q = (uint32_t)(((uint64_t)a.l[N - 1] * M) >> 52);
+    E r;
+    int64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      const int64_t t = (int64_t)a.l[j] - (int64_t)((uint64_t)q * F::P[j]) + c;
+      r.l[j] = (uint32_t)t & MASK;
+      c = t >> L;
+    }
+    r.l[N - 1] = (uint32_t)((int64_t)a.l[N - 1] - (int64_t)((uint64_t)q * F::P[N - 1]) + c);
+    return reduce(r);
+  }
   static KZG_HD bool is_zero(const E& a) {
     const E r = reduce(a);
     uint32_t acc = 0;

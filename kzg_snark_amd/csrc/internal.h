@@ -29,7 +29,7 @@ struct NttDomain {
   uint32_t* d_stage = nullptr;   // [2^(kmax-1)][9] Montgomery limbs
   uint32_t* d_twA = nullptr;     // [2^(log_n-h)][9]  (w^(2^h))^u  (x n^-1 when inverse)
   uint32_t* d_twB = nullptr;     // [2^h][9]          w^l
-  uint32_t* d_scale = nullptr;   // [9] multiplier of the last pass: Montgomery 1, or n^-1 when inverse
+  uint32_t* d_scale = nullptr;   // [9] n^-1 for a single-pass inverse transform; null: the last pass only reduces
   uint32_t* d_twist = nullptr;   // [n][9] w^(t*v) for two-pass sizes (row t of N2 entries)
   uint64_t last_use = 0;
 };

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     __syncthreads();
   }
 
-  // ---- store: one multiplication (twist or final scale) reduces the lazy value below 2p
+  // ---- store: the twist multiplication (or n^-1) reduces the lazy value below 2p; a factor of 1 is a plain reduction
   for (uint32_t idx = tid; idx < TILE; idx += T) {
     uint32_t line, pos;
     if (a.c_fast_store) { line = idx & (C - 1); pos = idx >> logC; }
@@ -186,11 +186,12 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
     if (a.twist) {
       const uint64_t col = a.col_base + tile * C + line;
-      x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
+      x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N)));
+    } else if (a.scale) {
+      x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.scale)));      // single-pass inverse: n^-1
     } else {
-      x = Fd::mul(x, glb_get_limbs<F>(a.scale));
+      x = Fd::reduce_wide(x);                                     // factor 1: reduce the lazy sum directly
     }
-    x = Fd::reduce(x);
     uint32_t w[8];
     Fd::to_words(x, w);
     uint4* g = reinterpret_cast<uint4*>(dst + (line * a.st_line + pos * a.st_pos) * 8);
@@ -251,7 +252,8 @@ int build_domain(Ctx* c, NttDomain& d) {
   std::vector<Job> jobs;
   if (d.kmax >= 1) jobs.push_back({&d.d_stage, pow2k(w, log_n - d.kmax), Fd::one(), 1u << (d.kmax - 1)});
   if (two_pass) {
-    jobs.push_back({&d.d_twA, pow2k(w, d.h), Fd::one(), 1u << (log_n - d.h)});
+    // the n^-1 of an inverse transform (fft_ff.py:57-58) rides on the twist: twist = n^-1 * w^(t*v)
+    jobs.push_back({&d.d_twA, pow2k(w, d.h), d.inverse ? ninv : Fd::one(), 1u << (log_n - d.h)});
     jobs.push_back({&d.d_twB, w, Fd::one(), 1u << d.h});
   }
   uint32_t* d_tmp = nullptr;
@@ -281,10 +283,15 @@ int build_domain(Ctx* c, NttDomain& d) {
     KZG_HIP(c, hipFree(d.d_twB));
     d.d_twA = d.d_twB = nullptr;
   }
-  // multiplier of the last pass: Montgomery 1 (forward) or n^-1 (inverse, fft_ff.py:57-58)
-  const Fe<F> last = Fd::reduce(d.inverse ? ninv : Fd::one());
-  KZG_HIP(c, hipMalloc(&d.d_scale, F::N * 4));
-  KZG_HIP(c, hipMemcpy(d.d_scale, last.l, F::N * 4, hipMemcpyHostToDevice));
+  // Last pass: a forward transform, and an inverse one whose n^-1 is already in the twist, end with the
+  // plain reduction of the lazy value (d_scale stays null); only the single-pass inverse multiplies by
+  // n^-1 (fft_ff.py:57-58).
+  d.d_scale = nullptr;
+  if (d.inverse && !two_pass) {
+    const Fe<F> last = Fd::reduce(ninv);
+    KZG_HIP(c, hipMalloc(&d.d_scale, F::N * 4));
+    KZG_HIP(c, hipMemcpy(d.d_scale, last.l, F::N * 4, hipMemcpyHostToDevice));
+  }
   return KZG_OK;
 }
 
@@ -368,9 +375,10 @@ int get_domain(Ctx* c, uint32_t log_n, const uint32_t* w_words, int inverse, Ntt
 
 // Distributed four-step NTT, local halves (kzg_snark_amd/sharding.py moves the data between them):
 //   columns: in-place N1-point transforms down the n_cols columns of an [N1][n_cols] matrix whose
-//            first column is global column col_base, followed by the twist w^(t * global column);
+//            first column is global column col_base, followed by the twist w^(t * global column)
+//            (times n^-1 for the inverse transform);
 //   rows:    in-place N2-point transforms along the n_rows rows of an [n_rows][N2] matrix, natural
-//            order in and out, followed by the final scale (1, or n^-1 for the inverse transform).
+//            order in and out, ending with the reduction of the lazily accumulated values.
 template <class F>
 int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
                   uint64_t count, uint64_t col_base) {

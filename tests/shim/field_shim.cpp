@@ -40,6 +40,17 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     case 15: R = Fd::sqr(Fd::template sub_carry<8>(A, Fd::template sub_carry<6>(B, A))); break;   // (2a - b)^2
     case 16: R = Fd::mul2(Fd::template sub_carry<2>(A, B), Fd::template sub_carry<8>(A, Fd::template sub_carry<6>(B, A)),
                           Fd::neg_weak(A), B); break;                       // (a - b)(2a - b) - a*b
+    case 17: {  // reduce_wide on a lazily accumulated value: 16a + 15b (< 62p), and on small ones
+      auto x = A;
+      for (int i = 0; i < 4; ++i) x = Fd::carry(Fd::add_lazy(Fd::add_lazy(x, x), B));
+      R = Fd::reduce_wide(x);
+      if (!(Fd::eq(Fd::reduce_wide(A), A) && Fd::eq(Fd::reduce_wide(Fd::carry(Fd::add_lazy(A, B))), Fd::add(A, B))))
+        R = Fd::zero();
+      // the result must be canonical: reducing again changes nothing, limb for limb
+      auto again = Fd::reduce(R);
+      for (int j = 0; j < F::N; ++j) if (again.l[j] != R.l[j]) R = Fd::zero();
+      break;
+    }
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
     if (a.twist) {
       const uint64_t col = a.col_base + tile * C + line;
-      x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N)));
+      // weak-normal (< 2p < 2^256) is enough between the passes: the next pass starts its lazy
+      // levels from it (2p + 4p per level stays below the 64p that reduce_wide accepts)
+      x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
     } else if (a.scale) {
       x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.scale)));      // single-pass inverse: n^-1
     } else {

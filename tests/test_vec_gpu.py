@@ -43,6 +43,18 @@ def test_vector_primitives(native, curve, n):
     ctx.vec_inverse(n, da.data_ptr(), out.data_ptr())
     ctx.synchronize()
     assert host(native, out) == [pow(x, -1, r) if x else 0 for x in a]
+    inpl = da.clone()                                      # in place (out aliases the input)
+    ctx.vec_inverse(n, inpl.data_ptr(), inpl.data_ptr())
+    ctx.synchronize()
+    assert host(native, inpl) == [pow(x, -1, r) if x else 0 for x in a]
+    if n >= 33:                                            # a whole chunk of zeros, and zeros at chunk borders
+        az = list(a)
+        for i in list(range(0, 32)) + [32, n - 1]:
+            az[i] = 0
+        dz = dev(native, az)
+        ctx.vec_inverse(n, dz.data_ptr(), out.data_ptr())
+        ctx.synchronize()
+        assert host(native, out) == [pow(x, -1, r) if x else 0 for x in az]
     ctx.vec_prefix_product(n, db.data_ptr(), out.data_ptr())
     ctx.synchronize()
     want, acc = [], 1

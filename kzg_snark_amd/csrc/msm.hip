@@ -315,7 +315,8 @@ template <class C, int WB>
 __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* recs, const uint32_t* vals,
                                                              const uint32_t* bstart, const uint32_t* order,
                                                              const uint32_t* slice_off, uint32_t* partials,
-                                                             uint32_t* buckets, uint32_t* chunk_counter) {
+                                                             uint32_t* buckets, uint32_t* chunk_counter,
+                                                             const uint32_t* chunk_rank) {
   using F = typename C::Fp;
   using Fd = Field<F>;
   using St = RecStage<C>;
@@ -331,8 +332,9 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
     if ((uint64_t)chunk * 64 >= total) break;          // every wave reaches this: the counter only grows
     const uint32_t t = chunk * 64 + lane;
     if (t >= total) continue;
-    // rank of the bucket of slice t: largest r with slice_off[r] <= t
-    uint32_t lo = 0, hi = NB;
+    // rank of the bucket of slice t: largest r with slice_off[r] <= t.  Every non-empty bucket has a
+    // slice, so it lies within `lane` ranks of the chunk's first one (chunk_rank, from stage P).
+    uint32_t lo = chunk_rank[chunk], hi = min(lo + lane + 1u, NB);
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
       if (slice_off[mid] <= t) lo = mid; else hi = mid;
@@ -689,7 +691,7 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 constexpr int NSLOT = 4;
 
 struct MsmSlot {
-  DevBuf prep_ws, vals, bstart, order, slice_off, counter;                          // prep
+  DevBuf prep_ws, vals, bstart, order, slice_off, counter, chunk_rank;              // prep
   DevBuf partials, buckets, rowsum, colsum, rowpart, colpart, tb;
   void* h_tb = nullptr;        // pinned host copy of the partial points
   hipEvent_t ev_in = nullptr;  // inputs ready on the context's stream
@@ -717,7 +719,7 @@ void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
   for (auto& sl : w->slot) {
-    for (DevBuf* b : {&sl.prep_ws, &sl.vals, &sl.bstart, &sl.order, &sl.slice_off, &sl.counter, &sl.partials,
+    for (DevBuf* b : {&sl.prep_ws, &sl.vals, &sl.bstart, &sl.order, &sl.slice_off, &sl.counter, &sl.chunk_rank, &sl.partials,
                       &sl.buckets, &sl.rowsum, &sl.colsum, &sl.rowpart, &sl.colpart, &sl.tb})
       hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
@@ -752,6 +754,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.colpart, (size_t)(NB / RC_CH) * PT))) return rc;
   if ((rc = ensure_buf(c, sl.tb, (size_t)MAX_NPART * PT))) return rc;
   if ((rc = ensure_buf(c, sl.counter, 256))) return rc;
+  const uint32_t nchunk_max = max_slices / 64 + 1;
+  if ((rc = ensure_buf(c, sl.chunk_rank, (size_t)nchunk_max * 4))) return rc;
   if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
     if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -778,7 +782,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));
   KZG_HIP(c, hipStreamWaitEvent(sp, sl.ev_in, 0));
   if ((rc = msm_prep_enqueue(c, sp, WB, d_scalars, n, (uint32_t)s->n, W::SEG, sl.prep_ws.p, vals, bstart, order,
-                             slice_off, static_cast<uint32_t*>(sl.counter.p))))
+                             slice_off, static_cast<uint32_t*>(sl.counter.p),
+                             static_cast<uint32_t*>(sl.chunk_rank.p), nchunk_max)))
     return rc;
   KZG_HIP(c, hipEventRecord(sl.ev_p, sp));
   KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
@@ -790,7 +795,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
     hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3(std::min(w->acc_blocks, (max_slices + 127) / 128)),
                        dim3(128), 0, sa, s->recs, vals, bstart, order, slice_off,
                        static_cast<uint32_t*>(sl.partials.p), static_cast<uint32_t*>(sl.buckets.p),
-                       static_cast<uint32_t*>(sl.counter.p));
+                       static_cast<uint32_t*>(sl.counter.p), static_cast<const uint32_t*>(sl.chunk_rank.p));
   }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipEventRecord(sl.ev_a, sa));

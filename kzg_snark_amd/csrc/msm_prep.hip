@@ -330,6 +330,28 @@ __global__ __launch_bounds__(TPB) void prep_ns_kernel(const uint32_t* bstart, co
   ns[r] = (bstart[k + 1] - bstart[k] + seg - 1) / seg;
 }
 
+// chunk_rank[c] = rank (position in length order) of the bucket that owns slice 64*c, the first slice
+// of the accumulate kernel's work chunk c: the kernel's lanes then search only the 64 ranks from there
+// instead of all NB (every non-empty bucket has at least one slice, so slice 64*c + l belongs to one of
+// the ranks chunk_rank[c] .. chunk_rank[c] + l).
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_chunk_rank_kernel(const uint32_t* slice_off, uint32_t nchunk_max,
+                                                              uint32_t* chunk_rank) {
+  constexpr uint32_t NB = PW<WB>::NB;
+  side_priority();
+  const uint32_t c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= nchunk_max) return;
+  const uint32_t t = c * 64u;
+  uint32_t lo = 0, hi = NB;
+  if (t < slice_off[NB]) {
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (slice_off[mid] <= t) lo = mid; else hi = mid;
+    }
+  }
+  chunk_rank[c] = lo;
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <int WB>
@@ -369,7 +391,7 @@ struct Layout {
 template <int WB>
 int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n, uint32_t seg,
                    void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
-                   uint32_t* chunk_counter) {
+                   uint32_t* chunk_counter, uint32_t* chunk_rank, uint32_t nchunk_max) {
   using P = PW<WB>;
   const Layout<WB> L(n);
   char* w = static_cast<char*>(ws);
@@ -416,6 +438,8 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
     size_t tb = L.scan_tmp_bytes;
     KZG_HIP(c, rocprim::exclusive_scan(w + L.off_scan_tmp, tb, ns, slice_off, 0u, (size_t)P::NB + 1,
                                        rocprim::plus<uint32_t>(), sp));
+    hipLaunchKernelGGL(prep_chunk_rank_kernel<WB>, dim3((nchunk_max + TPB - 1) / TPB), dim3(TPB), 0, sp, slice_off,
+                       nchunk_max, chunk_rank);
   }
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
@@ -429,10 +453,11 @@ size_t msm_prep_workspace_bytes(uint32_t n, int win_bits) {
 
 int msm_prep_enqueue(Ctx* c, hipStream_t sp, int win_bits, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n,
                      uint32_t seg, void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
-                     uint32_t* chunk_counter) {
-  return win_bits == 20
-             ? prep_enqueue_t<20>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off, chunk_counter)
-             : prep_enqueue_t<16>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off, chunk_counter);
+                     uint32_t* chunk_counter, uint32_t* chunk_rank, uint32_t nchunk_max) {
+  return win_bits == 20 ? prep_enqueue_t<20>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off,
+                                             chunk_counter, chunk_rank, nchunk_max)
+                        : prep_enqueue_t<16>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off,
+                                             chunk_counter, chunk_rank, nchunk_max);
 }
 
 }  // namespace kzg

@@ -43,7 +43,8 @@ def test_vector_primitives(native, curve, n):
     ctx.vec_inverse(n, da.data_ptr(), out.data_ptr())
     ctx.synchronize()
     assert host(native, out) == [pow(x, -1, r) if x else 0 for x in a]
-    inpl = da.clone()                                      # in place (out aliases the input)
+    inpl = dev(native, a)                                  # in place (out aliases the input); a blocking upload:
+                                                           # a clone() would run on torch's stream, not the library's
     ctx.vec_inverse(n, inpl.data_ptr(), inpl.data_ptr())
     ctx.synchronize()
     assert host(native, inpl) == [pow(x, -1, r) if x else 0 for x in a]

@@ -80,6 +80,15 @@ int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], i
 int kzg_ntt_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                    uint32_t batch);
 
+/* fft_ff / ifft_ff for ANY list length n >= 1 (fft_ff.py:3-58 never checks it): powers of two go
+ * to the kernels above; other lengths reproduce the reference recursion level by level -- slices of
+ * ceil(n/2) and floor(n/2) elements, n//2 butterflies, result[n-1] left at zero for odd n
+ * (fft_ff.py:20-35) -- which is what marlin/prover.py:439-449 receives when it passes list(row_A)
+ * with trailing zeros dropped.  inverse: root w^-1, scale by F(n)^-1 (fft_ff.py:53-58).
+ * n = 0 is KZG_ERR_ARG (the reference recurses without end). */
+int kzg_fft_ff_any(kzg_ctx* ctx, uint64_t* data, size_t n, const uint64_t w[4], int inverse);
+int kzg_fft_ff_any_device(kzg_ctx* ctx, void* d_data, size_t n, const uint64_t w[4], int inverse);
+
 /* The two local halves of the multi-GPU four-step transform of n = 2^log_n = N1*N2 elements
  * (N1 = 2^ceil(log_n/2)); kzg_snark_amd/sharding.py exchanges the data between them with
  * all-to-all transposes.  Requires log_n > 12.

@@ -34,6 +34,8 @@ SIGNATURES = {
     "kzg_ctx_destroy": (None, [_vp]),
     "kzg_last_error": (ctypes.c_char_p, [_vp]),
     "kzg_ctx_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "kzg_fft_ff_any": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_int]),
+    "kzg_fft_ff_any_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_int]),
     "kzg_ctx_synchronize": (ctypes.c_int, [_vp]),
     "kzg_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int]),
     "kzg_ntt_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint32]),
@@ -140,6 +142,7 @@ class Context:
         if curve_type not in CURVE_IDS:
             raise ValueError(f"Unsupported curve type: {curve_type}")    # kzg.py:37
         self.curve_type = curve_type
+        self.device = int(device)
         self.curve_id = CURVE_IDS[curve_type]
         self.fp_limbs = lib().kzg_fp_limbs(self.curve_id)
         h = ctypes.c_void_p()
@@ -170,6 +173,20 @@ class Context:
     def set_stream(self, stream_ptr):
         self._check(lib().kzg_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
 
+    def bind_torch_stream(self, stream=None):
+        """Run this context's work on a torch stream (default: torch's CURRENT stream on the
+        context's device) so that tensors produced or consumed by torch ops are ordered with the
+        engine's kernels without explicit synchronisation.  A fresh context owns a private
+        non-blocking stream: a torch producer on another stream then needs torch.cuda.synchronize()
+        (or an event) before the engine reads its output -- INTEGRATION.md, "stream ordering".
+        Returns the torch stream that was bound."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        self.set_stream(stream.cuda_stream)
+        self._torch_stream = stream            # keep the handle alive as long as it is bound
+        return stream
+
     def synchronize(self):
         self._check(lib().kzg_ctx_synchronize(self._h))
 
@@ -191,6 +208,11 @@ class Context:
         """data: C-contiguous uint64[n,4] numpy array, transformed in place."""
         assert data.dtype == np.uint64 and data.flags.c_contiguous and data.size == 4 << log_n
         self._check(lib().kzg_ntt(self._h, _as_vp(data), log_n, _as_vp(w_words), int(bool(inverse))))
+
+    def fft_ff_any(self, data, w_words, inverse):
+        """fft_ff / ifft_ff of a list of ANY length >= 1 (reference recursion semantics), in place."""
+        assert data.dtype == np.uint64 and data.flags.c_contiguous and data.ndim == 2 and data.shape[1] == 4
+        self._check(lib().kzg_fft_ff_any(self._h, _as_vp(data), data.shape[0], _as_vp(w_words), int(bool(inverse))))
 
     def ntt_device(self, d_ptr, log_n, w_words, inverse, batch=1):
         self._check(lib().kzg_ntt_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),

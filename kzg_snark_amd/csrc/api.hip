@@ -188,6 +188,35 @@ int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], i
   return KZG_OK;
 }
 
+int kzg_fft_ff_any_device(kzg_ctx* ctx, void* d_data, size_t n, const uint64_t w[4], int inverse) {
+  if (!ctx || !d_data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  if (n && !(n & (n - 1))) {   // power of two: the tiled kernels compute the same recursion
+    uint32_t log_n = 0;
+    while ((1ull << log_n) < n) ++log_n;
+    return ntt_run_device(c, static_cast<uint32_t*>(d_data), log_n, reinterpret_cast<const uint32_t*>(w),
+                          inverse ? 1 : 0, 1);
+  }
+  return fft_ragged_device(c, static_cast<uint32_t*>(d_data), n, reinterpret_cast<const uint32_t*>(w), inverse ? 1 : 0);
+}
+
+int kzg_fft_ff_any(kzg_ctx* ctx, uint64_t* data, size_t n, const uint64_t w[4], int inverse) {
+  if (!ctx || !data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  if (n == 0 || n > ((size_t)1 << 24)) return set_err(c, KZG_ERR_ARG, "kzg_fft_ff_any: length must be in [1, 2^24]");
+  KZG_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = n * 32;
+  int rc = ensure_buf(c, c->io, bytes);
+  if (rc) return rc;
+  KZG_HIP(c, hipMemcpyAsync(c->io.p, data, bytes, hipMemcpyHostToDevice, c->stream));
+  rc = kzg_fft_ff_any_device(ctx, c->io.p, n, w, inverse);
+  if (rc) return rc;
+  KZG_HIP(c, hipMemcpyAsync(data, c->io.p, bytes, hipMemcpyDeviceToHost, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  return KZG_OK;
+}
+
 int kzg_srs_load_g1(kzg_ctx* ctx, const uint64_t* xy, const uint8_t* inf, size_t n, kzg_srs** out) {
   if (!ctx || !xy || !out) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;

@@ -90,6 +90,7 @@ int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_w
                    uint32_t batch);
 int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
                        uint64_t count, uint64_t col_base);
+int fft_ragged_device(Ctx* c, uint32_t* d_data, uint64_t n, const uint32_t* w_words, int inverse);
 void ntt_free_domains(Ctx* c);
 
 // poly.hip: device vector / polynomial primitives over Fr

@@ -465,7 +465,109 @@ int get_domain(Ctx* c, uint32_t log_n, const uint32_t* w_words, int inverse, Ntt
   return KZG_OK;
 }
 
+
+// ---- arbitrary (non-power-of-two) lengths: the reference recursion level by level ---------------
+// fft_ff (fft_ff.py:15-37) never checks the length.  With n not a power of two its even/odd
+// slices have lengths ceil(n/2) and floor(n/2), the loop runs n//2 butterflies, and -- for odd n --
+// the last even value is dropped and result[n-1] stays F(0).  The output is not a transform of
+// anything, but it is what the reference returns (marlin/prover.py:439-449 passes list(row_A),
+// whose length is whatever survives Sage's dropping of trailing zeros), so the engine returns the
+// same values.  Off the hot path: one thread per output element and level, no LDS staging.
+//
+// The node at depth d reached by the slice choices (b0, .., b_(d-1)) holds the inputs j = off + k*2^d,
+// off = sum b_i 2^i, so it has L = ceil((n - off) / 2^d) elements; element k of its result is kept
+// at position off + k*2^d of a length-n buffer (the union of its children's positions).  A node with
+// L = 1 returns its input (fft_ff.py:16-17).  Depth d uses the root w^(2^d) (fft_ff.py:24).
+template <class F>
+__global__ void fft_ragged_level_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t n,
+                                        uint32_t d, const uint32_t* __restrict__ wd, const uint32_t* __restrict__ scale) {
+  using Fd = Field<F>;
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint64_t step = 1ull << d, off = p & (step - 1), k = p >> d;
+  const uint64_t len = (n - off + step - 1) >> d;
+  auto load = [&](uint64_t pos) {
+    const uint4* g = reinterpret_cast<const uint4*>(src + pos * 8);
+    const uint4 lo = g[0], hi = g[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return Fd::from_words(w);
+  };
+  Fe<F> out;
+  if (len == 1) {
+    out = load(p);                                          // fft_ff.py:16-17
+  } else {
+    const uint64_t h = len >> 1;                            // n // 2 butterflies (fft_ff.py:32)
+    if (k >= 2 * h) {
+      out = Fd::zero();                                     // odd length: result[n-1] keeps F(0) (fft_ff.py:29)
+    } else {
+      const uint64_t i = k < h ? k : k - h;
+      const Fe<F> e = load(off + ((2 * i) << d));           // even_fft[i]
+      const Fe<F> o = load(off + ((2 * i + 1) << d));       // odd_fft[i]
+      Fe<F> b = glb_get_limbs<F>(wd);                       // (w^(2^d))^i, Montgomery form
+      Fe<F> tw = Fd::one();
+      for (uint64_t bits = i; bits; bits >>= 1) {
+        if (bits & 1u) tw = Fd::mul(tw, b);
+        b = Fd::mul(b, b);
+      }
+      const Fe<F> t = Fd::mul(o, tw);                       // standard form * Montgomery form = standard form
+      out = k < h ? Fd::add(e, t) : Fd::sub(e, t);          // fft_ff.py:33-34
+    }
+  }
+  if (scale) out = Fd::mul(out, glb_get_limbs<F>(scale));   // ifft_ff: n^-1 (fft_ff.py:57-58)
+  out = Fd::reduce(out);
+  uint32_t w[8];
+  Fd::to_words(out, w);
+  uint4* g = reinterpret_cast<uint4*>(dst + p * 8);
+  g[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  g[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+template <class F>
+int fft_ragged_t(Ctx* c, uint32_t* d_data, uint64_t n, const uint32_t* w_words, int inverse) {
+  using Fd = Field<F>;
+  uint32_t depth = 0;
+  while ((1ull << depth) < n) ++depth;
+  Fe<F> w = Fd::to_mont(Fd::from_words(w_words));
+  if (inverse) w = Fd::inv(w);                                                     // fft_ff.py:53
+  std::vector<uint32_t> host((size_t)(depth + 1) * F::N);
+  for (uint32_t d = 0; d < depth; ++d) {
+    const Fe<F> wr = Fd::reduce(w);
+    memcpy(&host[(size_t)d * F::N], wr.l, F::N * 4);
+    w = Fd::mul(w, w);                                                             // fft_ff.py:24
+  }
+  if (inverse) {   // F(n)^-1 (fft_ff.py:57); n < 2^64 < r
+    const uint32_t nw[8] = {(uint32_t)n, (uint32_t)(n >> 32), 0, 0, 0, 0, 0, 0};
+    const Fe<F> ninv = Fd::reduce(Fd::inv(Fd::to_mont(Fd::from_words(nw))));
+    memcpy(&host[(size_t)depth * F::N], ninv.l, F::N * 4);
+  }
+  int rc = ensure_buf(c, c->ntt_scratch, (size_t)n * 32 + host.size() * 4 + 64);
+  if (rc) return rc;
+  uint32_t* scratch = static_cast<uint32_t*>(c->ntt_scratch.p);
+  uint32_t* d_tw = scratch + (((size_t)n * 8 + 15) & ~(size_t)15);
+  KZG_HIP(c, hipMemcpyAsync(d_tw, host.data(), host.size() * 4, hipMemcpyHostToDevice, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));   // `host` is a local buffer
+  uint32_t* bufs[2] = {d_data, scratch};
+  int cur = 0;
+  for (int d = (int)depth - 1; d >= 0; --d) {
+    const uint32_t* scale = (inverse && d == 0) ? d_tw + (size_t)depth * F::N : nullptr;
+    hipLaunchKernelGGL(fft_ragged_level_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       bufs[cur], bufs[cur ^ 1], n, (uint32_t)d, d_tw + (size_t)d * F::N, scale);
+    KZG_HIP(c, hipGetLastError());
+    cur ^= 1;
+  }
+  if (cur == 1) KZG_HIP(c, hipMemcpyAsync(d_data, scratch, (size_t)n * 32, hipMemcpyDeviceToDevice, c->stream));
+  return KZG_OK;
+}
+
 }  // namespace
+
+int fft_ragged_device(Ctx* c, uint32_t* d_data, uint64_t n, const uint32_t* w_words, int inverse) {
+  if (n == 0) return set_err(c, KZG_ERR_ARG, "fft_ff of an empty list: the reference recursion never terminates");
+  if (n > (1ull << 24)) return set_err(c, KZG_ERR_ARG, "kzg_fft_ff_any: n > 2^24 not supported");
+  if (n == 1) return KZG_OK;                       // fft_ff.py:16-17; F(1)^-1 = 1
+  return c->curve == 0 ? fft_ragged_t<BnFr>(c, d_data, n, w_words, inverse)
+                       : fft_ragged_t<BlsFr>(c, d_data, n, w_words, inverse);
+}
 
 int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, uint32_t batch) {
   if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");

@@ -32,27 +32,26 @@ def _curve_for(F):
 
 
 def _transform(seq, w, F, inverse):
+    """Any length >= 1.  Powers of two run the tiled NTT kernels; other lengths run the
+    level-by-level kernel that reproduces the reference recursion's slicing (ceil/floor halves,
+    n//2 butterflies, result[n-1] = F(0) for odd n, fft_ff.py:20-35) -- the reference never checks
+    the length and marlin/prover.py:439-449 relies on that when it passes list(row_A)."""
     n = len(seq)
-    if isinstance(seq, np.ndarray) and seq.dtype == np.uint64 and seq.ndim == 2 and seq.shape[1] == 4:
-        # buffer fast path (Python-object marshalling costs far more than the
-        # transform): canonical little-endian limbs in, a new array of the same shape out
-        if n & (n - 1):
-            raise ValueError(f"fft_ff: length {n} is not a power of two")
-        curve, r = _curve_for(F)
-        data = np.ascontiguousarray(seq).copy()
-        _native.get_context(curve).ntt(data, n.bit_length() - 1, _native.int_to_words(int(w) % r), inverse)
-        return data
-    if n & (n - 1):
-        # The reference recursion silently mis-sizes odd splits (fft_ff.py:20-21 with
-        # result = [F(0)]*n) and returns values that are not a transform of anything;
-        # no in-tree caller passes such a length.  Refuse rather than guess.
-        raise ValueError(f"fft_ff: length {n} is not a power of two")
+    if n == 0:
+        # fft_ff.py:16-26 with n == 0 slices two empty lists and recurses on them without end
+        raise RecursionError("maximum recursion depth exceeded (fft_ff of an empty list)")
     curve, r = _curve_for(F)
-    log_n = n.bit_length() - 1
-    data = _native.ints_to_limbs([int(x) % r for x in seq])
     ww = _native.int_to_words(int(w) % r)
-    _native.get_context(curve).ntt(data, log_n, ww, inverse)
-    return [F(v) for v in _native.limbs_to_ints(data)]
+    ctx = _native.get_context(curve)
+    as_buffer = isinstance(seq, np.ndarray) and seq.dtype == np.uint64 and seq.ndim == 2 and seq.shape[1] == 4
+    # buffer fast path (SURVEY.md 7.2: Python-object marshalling costs far more than the
+    # transform): canonical little-endian limbs in, a new array of the same shape out
+    data = np.ascontiguousarray(seq).copy() if as_buffer else _native.ints_to_limbs([int(x) % r for x in seq])
+    if n & (n - 1):
+        ctx.fft_ff_any(data, ww, inverse)
+    else:
+        ctx.ntt(data, n.bit_length() - 1, ww, inverse)
+    return data if as_buffer else [F(v) for v in _native.limbs_to_ints(data)]
 
 
 def fft_ff(coeffs, w, F):

@@ -98,7 +98,9 @@ class Prover:
     def __init__(self, curve_type="bn254"):
         self.kzg = KZG(curve_type)
 
-    def prove(self, ipk, x, w):
+    def prove(self, ipk, x, w, blinders=None, trace=None):
+        """`blinders` (tests only) fixes b1..b11 of plonk/prover.py:72-75 and :346; `trace`, when a
+        dict, receives the challenges and every intermediate polynomial."""
         kzg, Fq, R, X = self.kzg, self.kzg.Fq, self.kzg.R, self.kzg.X
         ck, P = ipk["ck"], ipk["polynomials"]
         sub = ipk["subgroups"]
@@ -112,7 +114,8 @@ class Prover:
         m = len(full) // 3
         cols = [pad(full[i * m:(i + 1) * m], n, Fq) for i in range(3)]
         PI = dom.public_input_poly(R, x)
-        b = [Fq.random_element() for _ in range(11)]
+        b = [Fq.random_element() for _ in range(11)] if blinders is None else [Fq(v) for v in blinders]
+        assert len(b) == 11
 
         # round 1: wire polynomials (3 INTTs, 3 MSMs of degree n+1)
         wires = [(b[2 * i] * X + b[2 * i + 1]) * ZH + dom.interpolate(cols[i]) for i in range(3)]
@@ -167,6 +170,9 @@ class Prover:
                + alpha * alpha * dom.lagrange_1_at(zeta) * (z_p - 1)
                - (zn - 1) * (t_lo + zn * t_mid + zn * zn * t_hi))
         assert r_p(zeta) == 0, "r(zeta) should be zero"                             # plonk/prover.py:171
+        if trace is not None:
+            trace.update(beta=beta, gamma=gamma, alpha=alpha, zeta=zeta, v=v, evaluations=dict(ev), a=a_p, b=b_p,
+                         c=c_p, z=z_p, PI=PI, t=t_p, t_lo=t_lo, t_mid=t_mid, t_hi=t_hi, r=r_p)
         W_z = kzg.open(ck, [r_p, a_p, b_p, c_p, P["S_sigma1"], P["S_sigma2"]], zeta, v)
         W_zw = kzg.open(ck, [z_p], zeta * g, v)
         return {"commitments": dict(zip(("a", "b", "c"), wire_comms), z=z_comm,

@@ -166,7 +166,10 @@ class DeviceProver:
         alg.set_entries(out, ups)
         return out
 
-    def prove(self, ipk, x, w):
+    def prove(self, ipk, x, w, blinders=None, trace=None):
+        """plonk/prover.py:24-212.  `blinders` (tests only) fixes b1..b11 of plonk/prover.py:72-75 and
+        :346 in the reference's order; `trace`, when a dict, receives the challenges and the device
+        tensors of every intermediate polynomial so a test can compare them with the oracle."""
         kzg, Fq, alg = self.kzg, self.kzg.Fq, self.alg
         r = kzg.curve_order
         ck, C = ipk["ck"], ipk["coeffs"]
@@ -183,7 +186,8 @@ class DeviceProver:
         else:
             full_limbs = _native.ints_to_limbs([int(v) % r for v in list(x) + list(w)])
         assert full_limbs.shape[0] == 3 * n
-        b = [int(Fq.random_element()) for _ in range(11)]
+        b = [int(Fq.random_element()) for _ in range(11)] if blinders is None else [int(v) % r for v in blinders]
+        assert len(b) == 11
         ones = alg.const(n, 1)
         idH = alg.mul_powers(ones, g)                                         # g^i
 
@@ -279,6 +283,10 @@ class DeviceProver:
             (alpha * f1 + alpha * alpha * L1z, z_c), (-alpha * f2 * beta, C["S_sigma3"]),
             (-(zn - 1), t_lo), (-(zn - 1) * zn, t_mid), (-(zn - 1) * zn * zn, t_hi)])
         assert alg.eval(r_c, zeta) == 0, "r(zeta) should be zero"                       # plonk/prover.py:171
+        if trace is not None:
+            trace.update(beta=beta, gamma=gamma, alpha=alpha, zeta=zeta, v=v, evaluations=dict(ev),
+                         a=a_c, b=b_c, c=c_c, z=z_c, PI=PI_c, t=t_c[:3 * n + 6], t_lo=t_lo, t_mid=t_mid,
+                         t_hi=t_hi, r=r_c)
         polys = [r_c, a_c, b_c, c_c, C["S_sigma1"], C["S_sigma2"]]
         stride = n + 6
         pack = torch.stack([alg.padded(p, stride) for p in polys]).contiguous()

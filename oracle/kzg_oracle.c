@@ -197,19 +197,20 @@ static const curve_t* get_curve(int id) {
 static void fft_rec(const field_t* f, uint64_t* out, const uint64_t* in, size_t n, const uint64_t* w) {
   const int L = f->n;
   if (n == 1) { memcpy(out, in, L * 8); return; }                     /* :16-17 */
-  size_t h = n / 2;
-  uint64_t* even = (uint64_t*)malloc(h * L * 8);
+  /* No length check in the reference: coeffs[0::2] has ceil(n/2) entries, coeffs[1::2] floor(n/2),
+   * the loop runs n // 2 butterflies, and for odd n result[n-1] keeps its initial F(0). */
+  size_t h = n / 2, he = n - h;
+  uint64_t* even = (uint64_t*)malloc(he * L * 8);
   uint64_t* odd = (uint64_t*)malloc(h * L * 8);
-  uint64_t* ef = (uint64_t*)malloc(h * L * 8);
+  uint64_t* ef = (uint64_t*)malloc(he * L * 8);
   uint64_t* of = (uint64_t*)malloc(h * L * 8);
-  for (size_t i = 0; i < h; ++i) {                                    /* :20-21 */
-    memcpy(even + i * L, in + (2 * i) * L, L * 8);
-    memcpy(odd + i * L, in + (2 * i + 1) * L, L * 8);
-  }
+  for (size_t i = 0; i < he; ++i) memcpy(even + i * L, in + (2 * i) * L, L * 8);      /* :20 */
+  for (size_t i = 0; i < h; ++i) memcpy(odd + i * L, in + (2 * i + 1) * L, L * 8);    /* :21 */
   uint64_t w2[MAXL];
   f_mul(f, w2, w, w);                                                 /* :24 */
-  fft_rec(f, ef, even, h, w2);                                        /* :25 */
+  fft_rec(f, ef, even, he, w2);                                       /* :25 */
   fft_rec(f, of, odd, h, w2);                                         /* :26 */
+  memset(out, 0, n * L * 8);                                          /* :29 */
   uint64_t wp[MAXL], t[MAXL];
   memcpy(wp, f->r1, L * 8);                                           /* :30 */
   for (size_t i = 0; i < h; ++i) {                                    /* :32-35 */
@@ -224,7 +225,7 @@ static void fft_rec(const field_t* f, uint64_t* out, const uint64_t* in, size_t 
 /* data: n canonical Fr elements (4 limbs each), in place.  inverse: fft_ff.py:51-58 */
 int oracle_fft(int curve_id, uint64_t* data, size_t n, const uint64_t* w, int inverse) {
   const curve_t* cv = get_curve(curve_id);
-  if (!cv || n == 0 || (n & (n - 1))) return -1;
+  if (!cv || n == 0) return -1;   /* n == 0: the reference recursion never terminates */
   const field_t* f = &cv->fr;
   uint64_t* in = (uint64_t*)malloc(n * 32);
   uint64_t* out = (uint64_t*)malloc(n * 32);

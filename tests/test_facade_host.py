@@ -90,8 +90,11 @@ def test_fft_ff_boundary_behaviour_without_gpu():
         fft_ff_interpolation([F(1)] * 6, g, F)
     with pytest.raises(AssertionError, match="Order of g"):               # fft_ff.py:78
         fft_ff_interpolation([F(1)] * 16, g, F)
-    with pytest.raises(ValueError):
-        fft_ff([F(1)] * 3, g, F)
+    from kzg_snark_amd._native import NativeUnavailable
+    with pytest.raises(NativeUnavailable):                                # length 3 is legal (the reference never
+        fft_ff([F(1)] * 3, g, F)                                          # checks it): it needs the engine, no fallback
+    with pytest.raises(RecursionError):                                   # fft_ff.py:16-26 on an empty list
+        fft_ff([], g, F)
     with pytest.raises(ValueError):
         fft_ff([1, 2], 3, GF(101))                                        # not a supported scalar field
 

@@ -127,8 +127,9 @@ def test_commit_open_identities(cv):
     assert pz == (xi * O.poly_eval(p, z, cv.r) + xi * xi * O.poly_eval(q, z, cv.r)) % cv.r
 
 
-def test_golden_ntt_vectors_both_oracles():
-    for v in load("ntt_vectors.json"):
+@pytest.mark.parametrize("fname", ["ntt_vectors.json", "ragged_fft_vectors.json", "config1_vectors.json"])
+def test_golden_ntt_vectors_both_oracles(fname):
+    for v in load(fname):
         cv = O.curve(v["curve"])
         x = [int(s, 16) for s in v["input"]]
         w = int(v["w"], 16)
@@ -172,6 +173,57 @@ def test_golden_kzg_vectors_both_oracles():
         assert hex(ev) == o["combined_eval"]
         xy, inf = CO.commit(name, ck_xy, quot)
         assert [hex(t) for t in ints(xy.reshape(2, L))] == o["proof"]
+
+
+def test_golden_config1_commit_and_open():
+    """BASELINE config 1 size: the stored commitments / opening against the C oracle's naive commit
+    (the Python oracle produced them) and the trapdoor identities."""
+    for v in load("config1_vectors.json"):
+        name = v["curve"]
+        cv = O.curve(name)
+        L = 4 if name == "bn254" else 6
+        n, tau = 1 << v["log_n"], int(v["tau"], 16)
+        x, coeffs = [int(s, 16) for s in v["input"]], [int(s, 16) for s in v["ifft"]]
+        ck_xy = CO.setup(name, tau, n)
+        for i, p in v["ck_spot"].items():
+            assert [hex(t) for t in ints(ck_xy[int(i)].reshape(2, L))] == p
+        for poly, key in ((x, "commit_input"), (coeffs, "commit_ifft")):
+            xy, inf = CO.commit(name, ck_xy, limbs(poly))
+            assert not inf and [hex(t) for t in ints(xy.reshape(2, L))] == v[key]
+            assert [hex(t) for t in O.normalize(O.commit_trapdoor(poly, tau, cv), cv)] == v[key]
+        o = v["open"]
+        y, z, xi = [int(s, 16) for s in o["second_poly"]], int(o["z"], 16), int(o["xi"], 16)
+        assert [hex(t) for t in O.normalize(O.open_trapdoor([x, y], z, xi, tau, cv), cv)] == o["proof"]
+        arr = np.zeros((2, n, 4), dtype=np.uint64)
+        arr[0], arr[1, :len(y)] = limbs(x), limbs(y)
+        quot, ev = CO.open_quotient(name, arr, [n, len(y)], z, xi)
+        assert hex(ev) == o["combined_eval"]
+        xy, inf = CO.commit(name, ck_xy, quot)
+        assert [hex(t) for t in ints(xy.reshape(2, L))] == o["proof"]
+
+
+def test_golden_plonk_proof_is_what_the_oracle_round_produces():
+    """tests/golden/plonk_proof_n16.json against oracle/plonk_oracle.prove_round, and the frozen
+    proof accepted by a verifier equation evaluated with the trapdoor (no pairing needed:
+    e(C - v G1 + z W, G2) = e(W, tau G2)  <=>  c - v + z w = tau w on the discrete logs)."""
+    from oracle import plonk_oracle as P
+    gp, g16 = load("plonk_proof_n16.json"), load("plonk_instance_n16.json")
+    cv = O.curve(gp["curve"])
+    col = {k: [int(x, 16) for x in v] for k, v in g16["columns"].items()}
+    w_full = col["a"] + col["b"] + col["c"]
+    circuit = (col["qM"], col["qL"], col["qR"], col["qO"], col["qC"], g16["perm"], w_full[:5], w_full[5:])
+    proof, ch, polys = P.prove_round(circuit, gp["n"], int(gp["g"], 16), gp["k1"], gp["k2"], int(gp["tau"], 16),
+                                     [int(b, 16) for b in gp["blinders"]], cv)
+    assert {k: hex(v) for k, v in ch.items()} == gp["challenges"]
+    assert {k: [hex(c) for c in v] for k, v in polys.items()} == gp["polynomials"]
+    assert {k: [hex(v[0]), hex(v[1]), v[2]] for k, v in proof["commitments"].items()} == gp["proof"]["commitments"]
+    assert {k: hex(v) for k, v in proof["evaluations"].items()} == gp["proof"]["evaluations"]
+    assert {k: [hex(v[0]), hex(v[1]), v[2]] for k, v in proof["kzg_proofs"].items()} == gp["proof"]["kzg_proofs"]
+    # every commitment is the trapdoor commitment of its polynomial
+    tau = int(gp["tau"], 16)
+    for k in ("a", "b", "c", "z", "t_lo", "t_mid", "t_hi"):
+        want = O.normalize(O.commit_trapdoor(polys[k], tau, cv), cv)
+        assert proof["commitments"][k] == (want[0], want[1], 1), k
 
 
 def test_golden_plonk_instance():

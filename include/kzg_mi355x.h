@@ -103,6 +103,17 @@ int kzg_ntt_columns_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uin
                            uint64_t n_cols, uint64_t col_base);
 int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                         uint64_t n_rows);
+/* The rows half reading and writing the all-to-all buffers directly (no repacking copies):
+ *   d_src  [world][n_rows][N2/world]  what the columns -> rows all-to-all delivers: block h holds
+ *          columns h*N2/world .. of this rank's n_rows rows;
+ *   d_dst  blocked_out != 0: [world][n_rows][N2/world] over the OUTPUT index b (block h = outputs
+ *          h*N2/world ..), the send buffer of the all-to-all that restores natural order;
+ *          blocked_out == 0: [n_rows][N2] plain rows -- the "transposed" result layout: row t of
+ *          this rank holds result indices b*N1 + t, b = 0..N2-1 (commit against a key shard in the
+ *          same order, kzg_srs_generate_strided; two all-to-alls per transform instead of three).
+ * Out of place (d_src != d_dst); world: power of two dividing N2. */
+int kzg_ntt_rows_exchange_device(kzg_ctx* ctx, const void* d_src, void* d_dst, uint32_t log_n, const uint64_t w[4],
+                                 int inverse, uint64_t n_rows, uint32_t world, int blocked_out);
 
 /* ---- commitment key: the `ck` list of KZG.setup / KZG.commit (kzg.py:56-78, 80) ------
  * kzg_srs_load_g1 uploads n affine G1 points (xy: n x 2*FP_LIMBS limbs; inf: n flag bytes or
@@ -115,6 +126,13 @@ int kzg_srs_generate(kzg_ctx* ctx, const uint64_t tau[4], size_t n, kzg_srs** ou
 /* The slice [tau^(start+i) * G1], i = 0..n-1: one rank's shard of a key partitioned by
  * coefficient range across GPUs. */
 int kzg_srs_generate_range(kzg_ctx* ctx, const uint64_t tau[4], size_t start, size_t n, kzg_srs** out);
+/* Key points in a strided order: point i = tau^e * G1 with
+ *   e = start + (i / run_len) * outer_stride + (i % run_len) * inner_stride.
+ * The shard a rank needs to commit the "transposed" output of the distributed inverse NTT without
+ * reordering it: rows t0..t0+R-1 of N2 coefficients each, coefficient (t, b) having index b*N1 + t
+ * => start = t0, run_len = N2, inner_stride = N1, outer_stride = 1, n = R*N2. */
+int kzg_srs_generate_strided(kzg_ctx* ctx, const uint64_t tau[4], size_t start, size_t n, size_t run_len,
+                             size_t inner_stride, size_t outer_stride, kzg_srs** out);
 /* Read points [start, start+count) back as canonical affine coordinates. */
 int kzg_srs_export(kzg_ctx* ctx, const kzg_srs* srs, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
 size_t kzg_srs_size(const kzg_srs* srs);

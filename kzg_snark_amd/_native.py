@@ -42,6 +42,10 @@ SIGNATURES = {
     "kzg_ntt_columns_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.c_uint64]),
     "kzg_ntt_rows_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64]),
+    "kzg_ntt_rows_exchange_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
+                                                    ctypes.c_uint32, ctypes.c_int]),
+    "kzg_srs_generate_strided": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                                ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "kzg_srs_load_g1": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(_vp)]),
     "kzg_srs_free": (None, [_vp]),
     "kzg_srs_size": (ctypes.c_size_t, [_vp]),
@@ -226,6 +230,10 @@ class Context:
         self._check(lib().kzg_ntt_rows_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
                                               int(bool(inverse)), n_rows))
 
+    def ntt_rows_exchange_device(self, d_src, d_dst, log_n, w_words, inverse, n_rows, world, blocked_out):
+        self._check(lib().kzg_ntt_rows_exchange_device(self._h, _as_vp(d_src), _as_vp(d_dst), log_n, _as_vp(w_words),
+                                                       int(bool(inverse)), n_rows, world, int(bool(blocked_out))))
+
     # ---- SRS
     def srs_load_g1(self, xy, inf=None):
         """xy: uint64[n, 2*fp_limbs] affine canonical; inf: uint8[n] flags or None."""
@@ -240,6 +248,13 @@ class Context:
     def srs_generate(self, tau_words, n, start=0):
         h = ctypes.c_void_p()
         self._check(lib().kzg_srs_generate_range(self._h, _as_vp(tau_words), start, n, ctypes.byref(h)))
+        return Srs(self, h, n)
+
+    def srs_generate_strided(self, tau_words, start, n, run_len, inner_stride, outer_stride):
+        """point i = tau^(start + (i // run_len) * outer_stride + (i % run_len) * inner_stride) * G1"""
+        h = ctypes.c_void_p()
+        self._check(lib().kzg_srs_generate_strided(self._h, _as_vp(tau_words), start, n, run_len, inner_stride,
+                                                   outer_stride, ctypes.byref(h)))
         return Srs(self, h, n)
 
     # ---- commit / open on host buffers

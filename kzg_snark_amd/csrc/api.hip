@@ -171,6 +171,15 @@ int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64
                             inverse ? 1 : 0, 1, n_rows, 0);
 }
 
+int kzg_ntt_rows_exchange_device(kzg_ctx* ctx, const void* d_src, void* d_dst, uint32_t log_n, const uint64_t w[4],
+                                 int inverse, uint64_t n_rows, uint32_t world, int blocked_out) {
+  if (!ctx || !d_src || !d_dst || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return ntt_rows_exchange_device(c, static_cast<const uint32_t*>(d_src), static_cast<uint32_t*>(d_dst), log_n,
+                                  reinterpret_cast<const uint32_t*>(w), inverse ? 1 : 0, n_rows, world, blocked_out);
+}
+
 int kzg_ntt(kzg_ctx* ctx, uint64_t* data, uint32_t log_n, const uint64_t w[4], int inverse) {
   if (!ctx || !data || !w) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;
@@ -236,6 +245,19 @@ int kzg_srs_generate_range(kzg_ctx* ctx, const uint64_t tau[4], size_t start, si
   KZG_HIP(c, hipSetDevice(c->device));
   Srs* s = nullptr;
   int rc = srs_generate(c, tau, start, n, &s);
+  if (rc) return rc;
+  *out = new kzg_srs{s};
+  return KZG_OK;
+}
+
+int kzg_srs_generate_strided(kzg_ctx* ctx, const uint64_t tau[4], size_t start, size_t n, size_t run_len,
+                             size_t inner_stride, size_t outer_stride, kzg_srs** out) {
+  if (!ctx || !tau || !out || run_len == 0) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  *out = nullptr;
+  KZG_HIP(c, hipSetDevice(c->device));
+  Srs* s = nullptr;
+  int rc = srs_generate(c, tau, start, n, &s, run_len, inner_stride, outer_stride);
   if (rc) return rc;
   *out = new kzg_srs{s};
   return KZG_OK;

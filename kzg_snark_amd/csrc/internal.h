@@ -56,6 +56,7 @@ struct Ctx {
   std::string err;
   std::vector<NttDomain> domains;
   uint64_t tick = 0;
+  bool ntt_lds_attr_set = false;   // hipFuncAttributeMaxDynamicSharedMemorySize applies per device
   DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
   DevBuf io;              // staging for the host-pointer entry points
   DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
@@ -90,6 +91,8 @@ int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_w
                    uint32_t batch);
 int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
                        uint64_t count, uint64_t col_base);
+int ntt_rows_exchange_device(Ctx* c, const uint32_t* d_src, uint32_t* d_dst, uint32_t log_n, const uint32_t* w_words,
+                             int inverse, uint64_t n_rows, uint32_t world, int blocked_out);
 int fft_ragged_device(Ctx* c, uint32_t* d_data, uint64_t n, const uint32_t* w_words, int inverse);
 void ntt_free_domains(Ctx* c);
 

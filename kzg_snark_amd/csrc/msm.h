@@ -15,7 +15,10 @@ struct Srs {
 };
 
 int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out);
-int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out);
+// run_len = 0: the contiguous range tau^(start + i); otherwise record i = tau^(start + (i / run_len) * outer_stride +
+// (i % run_len) * inner_stride)
+int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out, size_t run_len = 0,
+                 size_t inner_stride = 1, size_t outer_stride = 0);
 int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, uint8_t* inf);
 void srs_free(Srs* s);
 

@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void gen_table_kernel(const uint32_t* g_rec, u
 // powers: canonical words of tau^i (computed by pow kernel below)
 template <class C>
 __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, const uint32_t* tau_mont,
-                                                           uint32_t* recs, size_t start, size_t n) {
+                                                           uint32_t* recs, size_t start, size_t n, size_t run_len,
+                                                           size_t inner_stride, size_t outer_stride) {
   using F = typename C::Fp;
   using Fr = typename C::Fr;
   using Fd = Field<F>;
@@ -242,7 +243,9 @@ __global__ __launch_bounds__(128) void srs_generate_kernel(const uint32_t* tab, 
   Fe<Fr> b, acc = Frd::one();
 #pragma unroll
   for (int j = 0; j < Fr::N; ++j) b.l[j] = tau_mont[j];
-  for (size_t bits = start + i; bits; bits >>= 1) {
+  // record i holds tau^e, e = start + (i / run_len) * outer_stride + (i % run_len) * inner_stride
+  // (a contiguous range: run_len = n, inner_stride = 1)
+  for (size_t bits = start + (i / run_len) * outer_stride + (i % run_len) * inner_stride; bits; bits >>= 1) {
     if (bits & 1u) acc = Frd::mul(acc, b);
     b = Frd::mul(b, b);
   }
@@ -601,7 +604,7 @@ static int srs_load_t(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, 
 
 template <class C>
 static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t start, size_t n, const uint64_t* gen_xy,
-                          Srs** out) {
+                          Srs** out, size_t run_len, size_t inner_stride, size_t outer_stride) {
   using F = typename C::Fp;
   using Fr = typename C::Fr;
   if (n == 0 || n * (size_t)16 >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "kzg_srs_generate: bad size");
@@ -625,7 +628,7 @@ static int srs_generate_t(Ctx* c, const uint32_t* tau_words, size_t start, size_
                      (size_t)1, d_bad);
   hipLaunchKernelGGL(gen_table_kernel<C>, dim3(32), dim3(256), 0, c->stream, d_g, d_tab);
   hipLaunchKernelGGL(srs_generate_kernel<C>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, c->stream, d_tab, d_tau,
-                     s->recs, start, n);
+                     s->recs, start, n, run_len, inner_stride, outer_stride);
   e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(set_err(c, KZG_ERR_HIP, "srs generate", e));
   cleanup();
@@ -645,10 +648,12 @@ static const uint64_t GEN_BLS[12] = {
 int srs_load(Ctx* c, const uint64_t* xy, const uint8_t* inf, size_t n, Srs** out) {
   return c->curve == 0 ? srs_load_t<Bn254>(c, xy, inf, n, out) : srs_load_t<Bls12_381>(c, xy, inf, n, out);
 }
-int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out) {
+int srs_generate(Ctx* c, const uint64_t* tau, size_t start, size_t n, Srs** out, size_t run_len, size_t inner_stride,
+                 size_t outer_stride) {
   const uint32_t* t = reinterpret_cast<const uint32_t*>(tau);
-  return c->curve == 0 ? srs_generate_t<Bn254>(c, t, start, n, GEN_BN254, out)
-                       : srs_generate_t<Bls12_381>(c, t, start, n, GEN_BLS, out);
+  if (run_len == 0) { run_len = n ? n : 1; inner_stride = 1; outer_stride = 0; }
+  return c->curve == 0 ? srs_generate_t<Bn254>(c, t, start, n, GEN_BN254, out, run_len, inner_stride, outer_stride)
+                       : srs_generate_t<Bls12_381>(c, t, start, n, GEN_BLS, out, run_len, inner_stride, outer_stride);
 }
 void srs_free(Srs* s) {
   if (!s) return;

@@ -64,6 +64,10 @@ struct NttPassArgs {
   uint64_t col_base;       // global index of this matrix's first column (distributed column pass)
   uint64_t ld_line, ld_pos, tile_ld;
   uint64_t st_line, st_pos, tile_st;
+  // Exchange layouts of the distributed transform: element `pos` of a line lives in block
+  // pos >> shift (blocks `*_hi` elements apart), at pos & mask inside it.  Plain layouts: shift = 31.
+  uint64_t ld_hi, st_hi;
+  uint32_t ld_shift, st_shift;
   uint64_t batch_stride;   // elements between transforms of a batch (blockIdx.y)
   uint32_t pair_tiles;     // g > 0: remap blockIdx so that each group of 2^g adjacent tiles lands on one XCD
 };
@@ -119,7 +123,8 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     uint32_t line, pos;
     if (a.c_fast_load) { line = idx & (C - 1); pos = idx >> logC; }
     else               { pos = idx & (LEN - 1); line = idx >> k; }
-    const uint4* g = reinterpret_cast<const uint4*>(src + (line * a.ld_line + pos * a.ld_pos) * 8);
+    const uint32_t pl = pos & ((1u << a.ld_shift) - 1u), ph = pos >> a.ld_shift;
+    const uint4* g = reinterpret_cast<const uint4*>(src + (line * a.ld_line + pl * a.ld_pos + ph * a.ld_hi) * 8);
     const uint4 lo = g[0], hi = g[1];
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     const uint32_t rpos = k ? (__brev(pos) >> (32 - k)) : 0u;
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     }
     uint32_t w[8];
     Fd::to_words(x, w);
-    uint4* g = reinterpret_cast<uint4*>(dst + (line * a.st_line + pos * a.st_pos) * 8);
+    const uint32_t pl = pos & ((1u << a.st_shift) - 1u), ph = pos >> a.st_shift;
+    uint4* g = reinterpret_cast<uint4*>(dst + (line * a.st_line + pl * a.st_pos + ph * a.st_hi) * 8);
     g[0] = make_uint4(w[0], w[1], w[2], w[3]);
     g[1] = make_uint4(w[4], w[5], w[6], w[7]);
   }
@@ -315,11 +321,10 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     const uint32_t tile_elems = 1u << (a.k + a.logC);
     const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 4));
     const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
-    static bool lds_attr_set = false;   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
-    if (!lds_attr_set) {
+    if (!c->ntt_lds_attr_set) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU); per device, so per context
       KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      lds_attr_set = true;
+      c->ntt_lds_attr_set = true;
     }
     ProfScope ps(c, "ntt_pass");
     hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
@@ -328,6 +333,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   };
   if (log_n <= (uint32_t)TILE_LOG) {
     NttPassArgs a{};
+    a.ld_shift = a.st_shift = 31;
     a.src = d_data; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.pair_tiles = 0;
     a.scale = d.d_scale; a.k = log_n; a.logC = 0; a.kmax = d.kmax; a.h = 0; a.c_fast_load = 0;
@@ -345,6 +351,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     const uint32_t tl = std::max<uint32_t>(k1, tile_log_pref());
     const uint32_t logC = std::min<uint32_t>(tl - k1, k2);
     NttPassArgs a{};
+    a.ld_shift = a.st_shift = 31;
     a.pair_tiles = (logC < 2 && ((N2 >> logC) % (8u << (2 - logC)) == 0)) ? 2 - logC : 0;
     a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twist = d.d_twist; a.twist_pitch = N2;
     a.scale = nullptr;
@@ -359,6 +366,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     const uint32_t tl = std::max<uint32_t>(k2, tile_log_pref());
     const uint32_t logC = std::min<uint32_t>(tl - k2, k1);
     NttPassArgs a{};
+    a.ld_shift = a.st_shift = 31;
     a.pair_tiles = (logC < 2 && ((N1 >> logC) % (8u << (2 - logC)) == 0)) ? 2 - logC : 0;
     a.src = scratch; a.dst = d_data; a.stage = d.d_stage; a.twist = nullptr; a.twist_pitch = 0;
     a.scale = d.d_scale;
@@ -381,9 +389,13 @@ int get_domain(Ctx* c, uint32_t log_n, const uint32_t* w_words, int inverse, Ntt
 //            (times n^-1 for the inverse transform);
 //   rows:    in-place N2-point transforms along the n_rows rows of an [n_rows][N2] matrix, natural
 //            order in and out, ending with the reduction of the lazily accumulated values.
+//   rows (exchange form): src is what the columns -> rows all-to-all delivers, [world][n_rows][N2/world]
+//            (block h = columns h*N2/world ..); dst is either the same blocked shape over the OUTPUT index
+//            (ready for the all-to-all that restores natural order) or plain [n_rows][N2] rows.
 template <class F>
 int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse, int rows_pass,
-                  uint64_t count, uint64_t col_base) {
+                  uint64_t count, uint64_t col_base, uint32_t* d_dst = nullptr, uint32_t world = 1,
+                  int blocked_out = 0) {
   if (log_n <= (uint32_t)TILE_LOG) return set_err(c, KZG_ERR_ARG, "distributed NTT needs log_n > 12");
   const uint32_t k1 = (log_n + 1) / 2, k2 = log_n - k1;
   const uint64_t N1 = 1ull << k1, N2 = 1ull << k2;
@@ -395,7 +407,8 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
   uint32_t lc = 0;
   while ((1ull << (lc + 1)) <= count) ++lc;
   NttPassArgs a{};
-  a.src = d_data; a.dst = d_data; a.stage = dom->d_stage; a.kmax = dom->kmax; a.h = 0; a.batch_stride = 0;
+  a.ld_shift = a.st_shift = 31;
+  a.src = d_data; a.dst = d_dst ? d_dst : d_data; a.stage = dom->d_stage; a.kmax = dom->kmax; a.h = 0; a.batch_stride = 0;
   a.pair_tiles = 0;
   uint64_t tiles;
   if (!rows_pass) {
@@ -411,16 +424,24 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
     a.k = k2; a.logC = logC; a.c_fast_load = 0; a.c_fast_store = 0;
     a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
     a.st_line = N2; a.st_pos = 1; a.tile_st = N2 << logC;
+    if (d_dst) {   // exchange form
+      if (world == 0 || (world & (world - 1)) || world > N2) return set_err(c, KZG_ERR_ARG, "world must be a power of two <= N2");
+      if (d_dst == d_data) return set_err(c, KZG_ERR_ARG, "rows exchange pass is out of place");
+      uint32_t lw = 0;
+      while ((N2 >> (lw + 1)) >= world) ++lw;           // W = N2 / world = 2^lw
+      const uint64_t W = 1ull << lw;
+      a.ld_line = W; a.tile_ld = W << logC; a.ld_shift = lw; a.ld_hi = count * W;
+      if (blocked_out) { a.st_line = W; a.tile_st = W << logC; a.st_shift = lw; a.st_hi = count * W; }
+    }
     tiles = count >> logC;
   }
   const uint32_t tile_elems = 1u << (a.k + a.logC);
   const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2));
   const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
+  if (!c->ntt_lds_attr_set) {
     KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    lds_attr_set = true;
+    c->ntt_lds_attr_set = true;
   }
   ProfScope ps(c, "ntt_pass");
   hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, 1), dim3(threads), lds_bytes, c->stream, a);
@@ -580,6 +601,15 @@ int ntt_partial_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t*
   if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");
   return c->curve == 0 ? ntt_partial_t<BnFr>(c, d_data, log_n, w_words, inverse, rows_pass, count, col_base)
                        : ntt_partial_t<BlsFr>(c, d_data, log_n, w_words, inverse, rows_pass, count, col_base);
+}
+
+int ntt_rows_exchange_device(Ctx* c, const uint32_t* d_src, uint32_t* d_dst, uint32_t log_n, const uint32_t* w_words,
+                             int inverse, uint64_t n_rows, uint32_t world, int blocked_out) {
+  if (log_n > 24) return set_err(c, KZG_ERR_ARG, "kzg_ntt: log_n > 24 not supported");
+  uint32_t* src = const_cast<uint32_t*>(d_src);
+  return c->curve == 0
+             ? ntt_partial_t<BnFr>(c, src, log_n, w_words, inverse, 1, n_rows, 0, d_dst, world, blocked_out)
+             : ntt_partial_t<BlsFr>(c, src, log_n, w_words, inverse, 1, n_rows, 0, d_dst, world, blocked_out);
 }
 
 void ntt_free_domains(Ctx* c) {

@@ -4,16 +4,28 @@ this is the MI355X design of SURVEY.md section 8e:
 
   * batch mode  -- the k polynomials of one commit call (3+1+3 per PLONK proof,
     plonk/prover.py:89,113,136) are dealt round-robin to the ranks, each rank runs
-    whole MSMs against a replicated SRS, and the k result points (<= 97 bytes each)
-    are all-gathered.  No data-path collective.
+    whole MSMs against a replicated SRS, and the k result points are all-gathered.
+    No data-path collective.
   * range mode  -- ONE polynomial and the SRS are partitioned by contiguous
     coefficient range; every rank runs a full local Pippenger over its slice and the
     G partial points are all-gathered and added on the host (the EC group law is not
     an RCCL reduction operator): G-1 point additions, latency only.
+  * distributed NTT -- four-step transform with all-to-all transposes (DistributedNTT).
+
+What crosses ranks outside the NTT is a handful of FIXED-SIZE byte records (a G1 point is
+97 bytes: x | y as 48-byte little-endian integers and a flag byte; a field element 32 bytes),
+all-gathered as uint8 tensors -- on the device for RCCL, on the host for gloo -- never pickled
+Python objects.
 
 The local commit is injected (`commit_fn`) so the exchange logic is testable on CPU
 with gloo; in production it is KZG.commit on this rank's GPU."""
+import torch
 import torch.distributed as dist
+
+COORD_BYTES = 48                       # BLS12-381 Fp; BN254 coordinates are zero-padded
+POINT_BYTES = 2 * COORD_BYTES + 1      # x | y | flag
+FLAG_POINT, FLAG_INFINITY, FLAG_ABSENT = 0, 1, 2
+FR_BYTES = 32
 
 
 def round_robin(n_items, world):
@@ -26,6 +38,40 @@ def range_of(rank, world, n):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_point(pt):
+    """(x, y, z) facade point (normalised: z = 1, or z = 0 for infinity) or None -> 97 bytes."""
+    if pt is None:
+        return bytes(2 * COORD_BYTES) + bytes([FLAG_ABSENT])
+    if int(pt[2]) == 0:
+        return bytes(2 * COORD_BYTES) + bytes([FLAG_INFINITY])
+    return (int(pt[0]).to_bytes(COORD_BYTES, "little") + int(pt[1]).to_bytes(COORD_BYTES, "little")
+            + bytes([FLAG_POINT]))
+
+
+def unpack_point(rec):
+    flag = rec[2 * COORD_BYTES]
+    if flag == FLAG_ABSENT:
+        return None
+    if flag == FLAG_INFINITY:
+        return (1, 1, 0)
+    return (int.from_bytes(rec[:COORD_BYTES], "little"), int.from_bytes(rec[COORD_BYTES:2 * COORD_BYTES], "little"), 1)
+
+
+def all_gather_bytes(payload, group=None):
+    """Every rank contributes `payload` (same length everywhere); returns the list of all ranks'
+    payloads in rank order.  One all_gather of a uint8 tensor: on the current CUDA device under
+    RCCL ("nccl"), on the host under gloo."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [bytes(payload)]
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t, group=group)
+    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 
 
 class DistributedCommitter:
@@ -45,23 +91,22 @@ class DistributedCommitter:
     def rank(self):
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
-    def _all_gather(self, obj):
-        if self.world == 1:
-            return [obj]
-        out = [None] * self.world
-        dist.all_gather_object(out, obj, group=self.group)
-        return out
+    def _gather(self, payload):
+        return all_gather_bytes(payload, self.group)
 
     def commit_batch(self, polynomials):
         """Every rank passes the same list; returns the full ordered list of commitments on every rank."""
-        owners = round_robin(len(polynomials), self.world)
-        mine = [i for i, o in enumerate(owners) if o == self.rank]
+        k, world = len(polynomials), self.world
+        mine = [i for i in range(k) if i % world == self.rank]
         local = self.commit_fn([polynomials[i] for i in mine]) if mine else []
-        gathered = self._all_gather(list(zip(mine, local)))
-        out = [None] * len(polynomials)
-        for part in gathered:
-            for i, pt in part:
-                out[i] = tuple(pt)
+        per_rank = (k + world - 1) // world                     # fixed record count: absent slots are flagged
+        payload = b"".join(pack_point(local[j] if j < len(local) else None) for j in range(per_rank))
+        out = [None] * k
+        for g, blob in enumerate(self._gather(payload)):
+            for j in range(per_rank):
+                pt = unpack_point(blob[j * POINT_BYTES:(j + 1) * POINT_BYTES])
+                if pt is not None:
+                    out[g + j * world] = pt
         return out
 
     def open_range(self, begin_fn, finish_fn, z, modulus, n_total):
@@ -70,43 +115,55 @@ class DistributedCommitter:
         begin_fn() -> int H_g: value at z of this rank's combined slice polynomial, local indexing
                       (kzg_open_shard_begin);
         finish_fn(carry, first_rank) -> (partial proof point, P(z) or None)   (kzg_open_shard_finish).
-        One exchange of a field element per rank, one of a point per rank.  Returns (proof, P(z))."""
+        One exchange of a field element per rank, one of a point (+ P(z)) per rank.  Returns (proof, P(z))."""
         world, rank = self.world, self.rank
-        H = self._all_gather(int(begin_fn()))
+        H = [int.from_bytes(b, "little") for b in self._gather(int(begin_fn()).to_bytes(FR_BYTES, "little"))]
         lo_hi = [range_of(g, world, n_total) for g in range(world)]
         hi = lo_hi[rank][1]
         carry = sum(H[g] * pow(z, lo_hi[g][0] - hi, modulus) for g in range(rank + 1, world)) % modulus
         part, ev = finish_fn(carry, rank == 0)
-        acc = self.zero
-        got = self._all_gather((tuple(part), ev))
-        for pt, _ in got:
-            acc = self.add_fn(acc, tuple(pt))
-        return acc, got[0][1]
+        payload = pack_point(part) + (b"\x00" * (FR_BYTES + 1) if ev is None
+                                      else b"\x01" + int(ev).to_bytes(FR_BYTES, "little"))
+        acc, ev0 = self.zero, None
+        for g, blob in enumerate(self._gather(payload)):
+            acc = self.add_fn(acc, unpack_point(blob[:POINT_BYTES]))
+            if g == 0 and blob[POINT_BYTES] == 1:
+                ev0 = int.from_bytes(blob[POINT_BYTES + 1:], "little")
+        return acc, ev0
 
     def commit_range(self, local_coeffs):
         """local_coeffs: this rank's contiguous slice of ONE polynomial (its SRS shard is what
         commit_fn commits against).  Returns the commitment to the whole polynomial on every rank."""
         part = self.commit_fn([local_coeffs])[0]
         acc = self.zero
-        for pt in self._all_gather(tuple(part)):
-            acc = self.add_fn(acc, tuple(pt))
+        for blob in self._gather(pack_point(part)):
+            acc = self.add_fn(acc, unpack_point(blob))
         return acc
 
 
 class DistributedNTT:
-    """Four-step NTT / INTT of n = 2^log_n = N1*N2 elements sharded over G ranks by contiguous
-    index range (natural order in, natural order out), G | N1 and G | N2:
+    """Four-step NTT / INTT of n = 2^log_n = N1*N2 elements (N1 = 2^ceil(log_n/2)) over G ranks,
+    G | N1 and G | N2.  Input: natural order, rank g holds the contiguous range
+    [g*n/G, (g+1)*n/G) = rows g*R1 .. of the N1 x N2 row-major view (R1 = N1/G, W = N2/G).
 
-        all-to-all   rows of the N1 x N2 view  ->  whole columns per rank
-        local        column transforms (length N1) + twist w^(t*v)        ops.columns(M, col_base)
-        all-to-all   back to whole rows per rank
-        local        row transforms (length N2) + final scale             ops.rows(T)
-        all-to-all   row t, index b  ->  position b*N1 + t of the natural-order result
+        pack         [R1][G][W] -> [G][R1][W]                    (the one local copy on the way in)
+        all-to-all   rows -> whole columns: every rank now holds [N1][W]
+        local        column transforms + twist w^(t*v)           ops.columns(M, col_base)      in place
+        all-to-all   columns -> rows; the buffer is sent as it lies ([G][R1][W] blocks are contiguous)
+        local        row transforms reading the received blocks where they landed
+                                                                  ops.rows_exchange(recv, out, G, blocked)
+      layout="transposed" stops here (TWO all-to-alls): the result is [R1][N2], row t_local holding
+        result indices b*N1 + (g*R1 + t_local), b = 0..N2-1.  The MSM does not care about order, so a
+        commitment of the coefficients uses a key shard generated in the same order
+        (kzg_srs_generate_strided: start = g*R1, run_len = N2, inner_stride = N1, outer_stride = 1).
+      layout="natural" (fft_ff's ordering, contiguous range per rank) needs what no 2-D split can
+        avoid: the row pass writes its output blocked by destination rank, a THIRD all-to-all moves
+        the blocks, and one local transpose [N1][W] -> [W][N1] finishes.
 
     Each all-to-all moves 1/G of the shard to every peer -- one xGMI link per peer, all links
     driven at once (it is per-link bound, so no ring).  The local halves are injected: the GPU
-    passes (GpuNttOps -> kzg_ntt_columns_device / kzg_ntt_rows_device) in production, the oracle in
-    the gloo tests.  Tensors are int64 [.., 4] views of canonical Fr elements."""
+    passes (GpuNttOps) in production, the oracle in the gloo tests.  Tensors are int64 [.., 4]
+    views of canonical Fr elements."""
 
     def __init__(self, ops, group=None, exchange=None):
         self.ops = ops
@@ -122,17 +179,18 @@ class DistributedNTT:
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
     def exchange(self, send):
-        """send[h] goes to rank h; returns recv with recv[h] = what rank h sent to us."""
+        """send[h] goes to rank h; returns recv with recv[h] = what rank h sent to us.
+        `send` must be contiguous: the callers build their buffers in block order."""
+        assert send.is_contiguous()
         if self._exchange is not None:
             return self._exchange(send)
         if self.world == 1:
             return send
-        import torch
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send.contiguous(), group=self.group)
+        dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
-    def transform(self, x_local, log_n, world=None, rank=None):
+    def transform(self, x_local, log_n, world=None, rank=None, layout="natural"):
         G = self.world if world is None else world
         g = self.rank if rank is None else rank
         k1 = (log_n + 1) // 2
@@ -140,25 +198,37 @@ class DistributedNTT:
         N1, N2 = 1 << k1, 1 << k2
         if N1 % G or N2 % G:
             raise ValueError("world size must divide both N1 and N2")
+        if layout not in ("natural", "transposed"):
+            raise ValueError("layout must be 'natural' or 'transposed'")
         R1, W = N1 // G, N2 // G
         assert x_local.shape == (R1 * N2, 4)
         # rows -> columns
         send = x_local.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()
-        M = self.exchange(send).reshape(N1, W, 4)
+        M = self.exchange(send).view(N1, W, 4)
         self.ops.columns(M, g * W)
-        # columns -> rows
+        # columns -> rows: rows h*R1 .. of M are one contiguous block
         recv = self.exchange(M.view(G, R1, W, 4))
-        T = recv.permute(1, 0, 2, 3).contiguous().view(R1, N2, 4)
-        self.ops.rows(T)
-        # (t, b) -> natural index b*N1 + t
-        send = T.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()
-        recv = self.exchange(send)
-        return recv.permute(2, 0, 1, 3).contiguous().view(W * N1, 4)
+        out = torch.empty_like(recv)
+        if layout == "transposed":
+            self.ops.rows_exchange(recv, out, G, False)
+            return out.view(R1 * N2, 4)
+        self.ops.rows_exchange(recv, out, G, True)              # [G][R1][W] over the output index
+        got = self.exchange(out)                                # block h: rows of rank h, our W outputs
+        # (h, t_local, b_local) -> natural index b_local*N1 + h*R1 + t_local
+        return got.view(N1, W, 4).permute(1, 0, 2).contiguous().view(W * N1, 4)
+
+
+def transposed_index(log_n, world, rank, i):
+    """Global coefficient index of element i of the layout="transposed" result on `rank`."""
+    k1 = (log_n + 1) // 2
+    N1, N2 = 1 << k1, 1 << (log_n - k1)
+    R1 = N1 // world
+    return (i % N2) * N1 + rank * R1 + i // N2
 
 
 class GpuNttOps:
     """Local halves of DistributedNTT on this rank's GPU (tensors on the context's device; the
-    context must share the torch stream: ctx.set_stream(torch.cuda.current_stream().cuda_stream))."""
+    context must share the torch stream: ctx.bind_torch_stream())."""
 
     def __init__(self, ctx, log_n, w_words, inverse):
         self.ctx, self.log_n, self.w, self.inverse = ctx, log_n, w_words, inverse
@@ -166,5 +236,7 @@ class GpuNttOps:
     def columns(self, M, col_base):
         self.ctx.ntt_columns_device(M.data_ptr(), self.log_n, self.w, self.inverse, M.shape[1], col_base)
 
-    def rows(self, T):
-        self.ctx.ntt_rows_device(T.data_ptr(), self.log_n, self.w, self.inverse, T.shape[0])
+    def rows_exchange(self, recv, out, world, blocked):
+        n_rows = recv.shape[1]
+        self.ctx.ntt_rows_exchange_device(recv.data_ptr(), out.data_ptr(), self.log_n, self.w, self.inverse, n_rows,
+                                          world, blocked)

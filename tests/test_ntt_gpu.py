@@ -146,13 +146,21 @@ def test_facade_signatures(native):
 
 @pytest.mark.parametrize("curve,log_n,world", [("bls12_381", 14, 2), ("bls12_381", 16, 4), ("bn254", 13, 2)])
 def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
-    """kzg_ntt_columns_device / kzg_ntt_rows_device under kzg_snark_amd.sharding.DistributedNTT:
+    """kzg_ntt_columns_device / kzg_ntt_rows_exchange_device under kzg_snark_amd.sharding.DistributedNTT:
     `world` Python threads play the ranks (one engine context each, all on cuda:0) and exchange
     through an in-process all-to-all.  The result must equal the single-GPU transform and, for a
-    slice, the oracle -- forward, inverse and with a w that is not a primitive root."""
+    slice, the oracle -- forward, inverse and with a w that is not a primitive root; in natural
+    order (three exchanges) and in the transposed layout (two).  The coefficients of the inverse
+    transform are then committed where they lie, against key shards generated in the same order
+    (kzg_srs_generate_strided): the partial points must add up to p(tau) G1."""
     import threading
     import torch
-    from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps
+    from kzg_snark_amd.kzg import KZG
+    from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps, transposed_index
+    kzg = KZG(curve)
+    tau = 0x7a75 * 0x10001 + log_n
+    k1 = (log_n + 1) // 2
+    N1, N2 = 1 << k1, 1 << (log_n - k1)
     cv = O.curve(curve)
     n = 1 << log_n
     rs = np.random.RandomState(log_n)
@@ -170,6 +178,8 @@ def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
         barrier = threading.Barrier(world)
         mailbox = [None] * world
         outs = [None] * world
+        outs_t = [None] * world
+        parts = [None] * world
         errs = []
 
         def run(rank):
@@ -190,10 +200,19 @@ def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
                     lo, hi = rank * n // world, (rank + 1) * n // world
                     xl = torch.from_numpy(raw[lo:hi].view(np.int64)).to("cuda:0")
                     d = DistributedNTT(GpuNttOps(ctx, log_n, ww, inverse), exchange=exchange)
-                    out = d.transform(xl, log_n, world=world, rank=rank)
+                    out = d.transform(xl.clone(), log_n, world=world, rank=rank)
                     stream.synchronize()
                     ctx.synchronize()
                     outs[rank] = out.cpu().numpy().view(np.uint64)
+                    out_t = d.transform(xl.clone(), log_n, world=world, rank=rank, layout="transposed")
+                    stream.synchronize()
+                    ctx.synchronize()
+                    outs_t[rank] = out_t.cpu().numpy().view(np.uint64)
+                    if inverse:          # commit the shard where it lies
+                        m = out_t.shape[0]
+                        shard = ctx.srs_generate_strided(native.int_to_words(tau), rank * (N1 // world), m, N2, N1, 1)
+                        parts[rank] = ctx.commit_device(shard, out_t.data_ptr(), [m], m)
+                        shard.close()
                 ctx.close()
             except Exception as e:  # noqa: BLE001
                 errs.append(repr(e))
@@ -207,3 +226,18 @@ def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
         assert not errs, errs
         got = np.concatenate(outs)
         assert np.array_equal(got, ref), (w == cases[2][0], inverse)
+        m = n // world
+        for rank in range(world):
+            idx = np.array([transposed_index(log_n, world, rank, i) for i in range(m)])
+            assert np.array_equal(outs_t[rank], ref[idx]), ("transposed layout", rank, inverse)
+        if inverse:
+            L = native.get_context(curve).fp_limbs
+            acc = kzg.Z1
+            for xy, inf in parts:
+                assert inf[0] == 0
+                v = native.limbs_to_ints(xy.reshape(2, L))
+                acc = kzg.add(acc, (v[0], v[1], 1))
+            p_tau = native.get_context(curve).poly_eval(n, torch.from_numpy(ref.view(np.int64)).to("cuda:0").data_ptr(), tau)
+            want = kzg._g1.normalize(kzg.multiply(kzg.G1, p_tau))
+            got_pt = kzg._g1.normalize(acc)
+            assert (int(got_pt[0]), int(got_pt[1])) == (int(want[0]), int(want[1])), "commit of the transposed shards"

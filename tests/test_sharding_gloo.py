@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
         n = 13
         full_ck = O.setup(n - 1, tau, cv)
         rng = random.Random(5)
-        polys = [[rng.randrange(cv.r) for _ in range(rng.randrange(1, n + 1))] for _ in range(5)]
+        polys = [[rng.randrange(cv.r) for _ in range(rng.randrange(1, n + 1))] for _ in range(4)] + [[0, 0]]
 
         def to_pt(p):
             a = O.normalize(p, cv)
@@ -124,14 +124,24 @@ class _OracleNttOps:
                 out[t * W + c] = col[t] * pow(self.w, t * (col_base + c), self.r) % self.r
         self._put(M, out)
 
-    def rows(self, T):
-        R1, N2 = T.shape[0], T.shape[1]
-        vals = self._ints(T)
+    def rows_exchange(self, recv, out, world, blocked):
+        """recv: [G][R1][W] blocks as the columns -> rows all-to-all delivers them; out: the same
+        blocked shape over the output index (blocked) or plain [R1][N2] rows."""
+        G, R1, W = recv.shape[0], recv.shape[1], recv.shape[2]
+        assert G == world
+        N2 = G * W
+        vals = self._ints(recv)
         root = pow(self.w, 1 << self.k1, self.r)
-        out = []
+        res = [0] * (R1 * N2)
         for t in range(R1):
-            out += [v * self.scale % self.r for v in O.fft_ff(vals[t * N2:(t + 1) * N2], root, self.r)]
-        self._put(T, out)
+            row = [vals[(v // W) * R1 * W + t * W + (v % W)] for v in range(N2)]
+            tr = [v * self.scale % self.r for v in O.fft_ff(row, root, self.r)]
+            for b in range(N2):
+                if blocked:
+                    res[(b // W) * R1 * W + t * W + (b % W)] = tr[b]
+                else:
+                    res[t * N2 + b] = tr[b]
+        self._put(out, res)
 
 
 def _ntt_worker(rank, world, port, q):
@@ -152,9 +162,13 @@ def _ntt_worker(rank, world, port, q):
             lo, hi = rank * n // world, (rank + 1) * n // world
             buf = b"".join(v.to_bytes(32, "little") for v in x[lo:hi])
             xl = torch.from_numpy(np.frombuffer(buf, dtype="<i8").reshape(hi - lo, 4).copy())
-            out = DistributedNTT(_OracleNttOps(log_n, w, cv.r, inverse)).transform(xl, log_n)
-            got = _OracleNttOps._ints(out)
+            d = DistributedNTT(_OracleNttOps(log_n, w, cv.r, inverse))
+            got = _OracleNttOps._ints(d.transform(xl.clone(), log_n))
             assert got == want[lo:hi], (inverse, "distributed NTT shard mismatch")
+            # two all-to-alls: the result stays in the row pass's order
+            from kzg_snark_amd.sharding import transposed_index
+            got_t = _OracleNttOps._ints(d.transform(xl.clone(), log_n, layout="transposed"))
+            assert got_t == [want[transposed_index(log_n, world, rank, i)] for i in range(hi - lo)], "transposed layout"
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -164,8 +178,9 @@ def _ntt_worker(rank, world, port, q):
 
 
 def test_two_rank_distributed_ntt():
-    """The all-to-all choreography of the multi-GPU four-step NTT (natural order in and out,
-    arbitrary w, inverse) with the oracle as the local transform."""
+    """The all-to-all choreography of the multi-GPU four-step NTT (natural order in; natural order
+    out with three exchanges or the transposed layout with two; arbitrary w, inverse) with the
+    oracle as the local transform."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

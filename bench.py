@@ -9,45 +9,178 @@ plonk/prover.py:89,113,136), inputs already resident in HBM:
     followed by one KZG.commit call on the B coefficient vectors against a 2^20-point SRS
     (kzg.py:80-120).
 
-`value` = commits/sec = polynomials committed per second over the whole job (all ranks).  N > 1: one process per GPU, every
-rank commits its own polynomial against a replicated SRS -- the path shards by polynomial
-with no data-path collective, so scaling is "weak".
+`value` = commits/sec = polynomials committed per second over the whole job (all ranks).  N > 1: one
+process per GPU, every rank commits its own polynomials against a replicated SRS -- the path shards by
+polynomial with no data-path collective, so scaling is "weak".  The last step's
+commitments are checked against the trapdoor identity commit(ck, p) = p(tau) G1 after the clock stops.
 
-Also reported on the same line: NTT Fr-elements/sec (the second half of BASELINE.json's
-metric), a roofline object for the dominant kernel (msm_accumulate, timed with HIP events
-on the library's stream inside the timed region), one for the NTT passes, and the CPU
-baseline (the oracle's C restatement of the reference algorithms, 1 core, bounded sample).
+The same JSON line also carries
+  * ntt_elements_per_s + roofline_ntt   the NTT half of BASELINE.json's metric, timed alone;
+  * roofline                             the dominant kernel (msm_accumulate), HIP events on its stream;
+  * open                                 KZG.open of k = 6 polynomials of 2^20 (plonk/prover.py:184): opens/s,
+                                         roofline of the lincomb/evaluate/divide kernels, verified;
+  * range_mode                           BASELINE config 4: ONE degree-2^24 polynomial set and its key split by
+                                         coefficient range over the ranks, commit + batched open per step,
+                                         verified against the trapdoor identities (n_gpus = 1: the whole job);
+  * distributed_ntt                      (N >= 2) the four-step 2^24 transform over RCCL all-to-all, verified
+                                         against the single-GPU transform;
+  * cpu_baseline / cpu_baseline_optimised   rank 0 at N = 1: the oracle's C restatement of the reference
+                                         algorithms on 1 core, and a multi-threaded Montgomery + Pippenger
+                                         CPU implementation on all host cores.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--curve bls12_381]
 
-`--mode range` is a second workload, not the headline line: ONE degree-2^log_n polynomial and its key
-split by coefficient range over the ranks, commit + batched open per step (BASELINE config 4, strong
-scaling), every result checked against the trapdoor identities; see run_range().
+--gpus N > 1 without a launcher (no WORLD_SIZE in the environment) starts N child processes, one per
+GPU, before this process has touched HIP; under torch.distributed.run it uses the ranks it is given
+and refuses to run when WORLD_SIZE != --gpus.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see kzg_snark_amd/_native.py: one HW queue per pipeline stream
-
-import numpy as np
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4   # wave64 VALU instructions/ns: 1024 SIMDs x 2.4 GHz / 4 cycles per instruction
 R_BLS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+TAU = 0x6b7a675f736e61726b7a675f736e6172
+Z_PT = 0x1111111111111111111111111111
+XI_PT = 0x2222222222222222222222
+DTYPE = "integer: 13x30-bit limbs in u32 (381-bit Fp), 9x29-bit limbs (255-bit Fr), 64-bit multiply-add"
 
 
 def root_of_unity(r, gen, n):
     return pow(gen, (r - 1) // n, r)
 
 
-def cpu_baseline(curve, log_n, r, omega):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--curve", default="bls12_381")
+    ap.add_argument("--batch", type=int, default=4, help="polynomials per step (one commit call)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the one-commit-at-a-time accumulate timing")
+    ap.add_argument("--no-open", action="store_true", help="skip the KZG.open section")
+    ap.add_argument("--no-range", action="store_true", help="skip the range-sharded config-4 section")
+    ap.add_argument("--no-dist-ntt", action="store_true", help="skip the distributed NTT section")
+    ap.add_argument("--range-log-n", type=int, default=24, help="degree of the range-sharded job (config 4: 24)")
+    ap.add_argument("--range-steps", type=int, default=5)
+    ap.add_argument("--open-k", type=int, default=6, help="polynomials per opening (plonk/prover.py:184 opens 6)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
+                                                      "multi-rank path with all ranks on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher self-test without a GPU: the ranks rendezvous over gloo, all-gather one record "
+                         "each and rank 0 prints one JSON line")
+    ap.add_argument("--mode", default="all", choices=("all", "batch", "range"),
+                    help="all (default): headline + every section; batch: headline only; range: the config-4 "
+                         "section only, printed as its own line")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: one process per GPU, started before anything here touches HIP
+# ------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_gpus():
+    """torch.cuda.device_count() in a short-lived child: this process must stay HIP-free, its
+    children are what touch the GPU (an exec/fork after HIP initialisation is not allowed here)."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def launch(args, argv):
+    n = args.gpus
+    if not (args.one_device or args.rehearse_launch):
+        have = visible_gpus()
+        if have < n:
+            print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run a smaller job "
+                  f"under that label", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:          # a rank failed: do not leave the others in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+def rehearse_launch(args, world, rank):
+    """No GPU: proves that the launcher's children rendezvous and that the fixed-size record
+    exchange works over gloo (tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    from kzg_snark_amd.sharding import all_gather_bytes
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = all_gather_bytes(bytes([rank]) * 4)
+    ok = got == [bytes([g]) * 4 for g in range(world)]
+    if rank == 0:
+        print(json.dumps({"launcher": "ok" if ok else "exchange mismatch", "world": world, "n_gpus": args.gpus}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only; bounded samples)
+# ------------------------------------------------------------------------------------------------
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(curve, log_n, omega):
     """oracle/kzg_oracle.c (reference algorithms, single thread) on a bounded sample."""
+    import numpy as np
     from oracle import c_oracle as CO
     n = 1 << log_n
     rs = np.random.RandomState(123)
@@ -73,143 +206,292 @@ def cpu_baseline(curve, log_n, r, omega):
                    f"linearly x{n // sample} to 2^{log_n} coefficients"),
         "ntt_elements_per_s": n / t_ntt,
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
     }
 
 
-def run_range(args, ctx, dev, world, rank, dist, torch, _native):
-    """BASELINE config 4: one polynomial of 2^log_n coefficients and its commitment key split by
-    contiguous coefficient range over the ranks.  Step = commit + open of that
-    polynomial: every rank runs a whole local MSM per operation; what crosses ranks is one field
-    element (open) and one point per rank per operation, added on the host by every rank."""
-    from kzg_snark_amd.kzg import KZG
-    from kzg_snark_amd.sharding import DistributedCommitter, range_of
-    kzg = KZG(args.curve)
-    r = kzg.curve_order
-    L = ctx.fp_limbs
-    n = 1 << args.log_n
+def cpu_baseline_optimised(curve, log_n, omega):
+    """oracle/fast_cpu.c: Montgomery limbs with unsigned __int128, iterative NTT, signed-window Pippenger,
+    OpenMP over all host cores -- the 'fair' CPU figure of BASELINE.md section 3.  Whole 2^log_n job."""
+    import numpy as np
+    try:
+        from oracle import fast_cpu as FC
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"oracle/fast_cpu unavailable: {e!r}"}
+    n = 1 << log_n
+    # the threads this process may really use: its affinity mask, capped at a one-GPU box's CPU share
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    rs = np.random.RandomState(321)
+    data = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    data[:, 3] >>= np.uint64(3)
+    t0 = time.perf_counter()
+    pts = FC.setup(curve, 0x1234567, n, threads=cores)
+    t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    FC.ntt(curve, data, omega, inverse=True, threads=cores)
+    t_ntt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    FC.msm(curve, pts, data, threads=cores)
+    t_msm = time.perf_counter() - t0
+    return {
+        "value": 1.0 / (t_ntt + t_msm),
+        "unit": "commits/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle/fast_cpu.cpp, {cores} threads (OpenMP): iterative INTT of 2^{log_n} ({t_ntt * 1e3:.0f} ms) + "
+                   f"Pippenger MSM of 2^{log_n} points ({t_msm:.2f} s), both measured in full, one repetition; "
+                   f"key generated in {t_setup:.1f} s"),
+        "ntt_elements_per_s": n / t_ntt,
+        "cpu_model": cpu_model(),
+    }
+
+
+# ------------------------------------------------------------------------------------------------
+# sections
+# ------------------------------------------------------------------------------------------------
+
+class Env:
+    """What every section needs: the context, the device, ranks, helpers."""
+
+    def __init__(self, args, torch, dist, ctx, dev, world, rank, native):
+        self.args, self.torch, self.dist, self.ctx, self.dev = args, torch, dist, ctx, dev
+        self.world, self.rank, self.native = world, rank, native
+        from kzg_snark_amd.kzg import KZG
+        self.kzg = KZG(args.curve)
+        self.r = self.kzg.curve_order
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], device=self.dev if self.args.backend == "nccl" else "cpu",
+                              dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def affine(self, pt):
+        q = self.kzg._g1.normalize(pt)
+        return (int(q[0]), int(q[1]))
+
+    def g1_times(self, s):
+        return self.affine(self.kzg.multiply(self.kzg.G1, s % self.r))
+
+    def point(self, xy, inf=0):
+        import numpy as np
+        if inf:
+            return self.kzg.Z1
+        v = self.native.limbs_to_ints(np.asarray(xy).reshape(2, self.ctx.fp_limbs))
+        return (v[0], v[1], 1)
+
+    def uniform(self, shape_prefix, seed):
+        """uniform-looking canonical Fr elements (< 2^251 < r) generated on the device."""
+        torch = self.torch
+        g = torch.Generator(device=self.dev).manual_seed(seed)
+        t = torch.randint(0, 1 << 62, (*shape_prefix, 4), generator=g, dtype=torch.int64, device=self.dev)
+        t[..., 3] >>= 3
+        return t
+
+
+def section_open(env, srs, n):
+    """KZG.open (kzg.py:122-159) of k polynomials of n coefficients: combine with xi^(i+1), evaluate at z,
+    divide by (X - z) -- csrc/poly.hip -- then one MSM."""
+    args, ctx, nat = env.args, env.ctx, env.native
+    k = args.open_k
+    polys = env.uniform((k, n), 0x6f70656e + env.rank)
+    lens = [n - i for i in range(k)]                     # ragged like the provers' n+2..n+6 (shorter ones read as zero-padded)
+    zw, xw = nat.int_to_words(Z_PT % env.r), nat.int_to_words(XI_PT % env.r)
+    env.torch.cuda.synchronize(env.dev)
+    for _ in range(2):
+        ctx.open(srs, polys.data_ptr(), lens, n, zw, xw, device=True)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    iters = max(5, min(args.steps, 20))
+    env.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        xy, inf, ev = ctx.open(srs, polys.data_ptr(), lens, n, zw, xw, device=True)
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    poly_ms, poly_cnt = ctx.prof_read("open_poly")
+    ctx.prof_enable(False)
+    # trapdoor: proof == ((P(tau) - P(z)) / (tau - z)) G1 with P = sum xi^(i+1) p_i
+    r, tau, z, xi = env.r, TAU % env.r, Z_PT % env.r, XI_PT % env.r
+    Pt = sum(pow(xi, i + 1, r) * ctx.poly_eval(lens[i], polys[i].data_ptr(), tau) for i in range(k)) % r
+    Pz = int.from_bytes(ev.tobytes(), "little")
+    ok = (not inf[0]) and env.affine(env.point(xy)) == env.g1_times((Pt - Pz) * pow((tau - z) % r, -1, r))
+    ok_ev = Pz == sum(pow(xi, i + 1, r) * ctx.poly_eval(lens[i], polys[i].data_ptr(), z) for i in range(k)) % r
+    alg_bytes = (k + 1) * n * 32                            # SURVEY.md 8d: read k polynomials, write the quotient
+    avg_s = poly_ms / max(poly_cnt, 1) * 1e-3
+    return {
+        "value": env.world * iters / elapsed, "unit": "opens/s", "k": k, "log_n": n.bit_length() - 1,
+        "ms_per_open": elapsed / iters * 1e3,
+        "poly_stage_ms": avg_s * 1e3,
+        "verified": {"proof_trapdoor": bool(ok), "combined_eval": bool(ok_ev)},
+        "roofline": {"kernel": "open_poly: lincomb + chunk_eval + scan + chunk_fill (csrc/poly.hip)", "bound": "hbm",
+                     "achieved": alg_bytes / avg_s / 1e9 if avg_s > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBPS if avg_s > 0 else None, "traffic": None,
+                     "algorithmic_bytes_per_open": alg_bytes},
+    }, bool(ok and ok_ev)
+
+
+def section_range(env):
+    """BASELINE config 4: k polynomials of 2^log_n coefficients and the commitment key split by contiguous
+    coefficient range over the ranks.  Step = commit of polynomial 0 + open of all k:
+    every rank runs a whole local MSM per operation; what crosses ranks is one field element (open) and one
+    point per rank per operation, all-gathered as fixed-size records and added on the host by every rank."""
+    from kzg_snark_amd.sharding import DistributedCommitter, all_gather_bytes, range_of
+    args, ctx, nat, kzg, r = env.args, env.ctx, env.native, env.kzg, env.r
+    world, rank = env.world, env.rank
+    log_n, k = args.range_log_n, args.open_k
+    n = 1 << log_n
     lo, hi = range_of(rank, world, n)
     m = hi - lo
-    tau = 0x6b7a675f736e61726b7a675f736e6172 % r
-    z, xi = 0x1111111111111111111111111111 % r, 0x2222222222222222222222 % r
-    tw, zw, xw = _native.int_to_words(tau), _native.int_to_words(z), _native.int_to_words(xi)
+    tau, z, xi = TAU % r, Z_PT % r, XI_PT % r
+    tw, zw, xw = nat.int_to_words(tau), nat.int_to_words(z), nat.int_to_words(xi)
     t0 = time.perf_counter()
     cshard = ctx.srs_generate(tw, m, start=lo)                      # tau^lo .. tau^(hi-1)
     start = 0 if rank == 0 else lo - 1
     oshard = ctx.srs_generate(tw, hi - 1 - start, start=start)      # key slice of the quotient's coefficients
     ctx.synchronize()
     t_srs = time.perf_counter() - t0
-    g = torch.Generator(device="cpu").manual_seed(0x6b7a + rank)
-    host = torch.randint(0, 1 << 62, (m, 4), generator=g, dtype=torch.int64)
-    host[:, 3] >>= 3
-    sl = host.to(dev)
-
-    def to_pt(xy, inf):
-        if inf:
-            return kzg.Z1
-        v = _native.limbs_to_ints(np.asarray(xy).reshape(2, L))
-        return (v[0], v[1], 1)
+    sl = env.uniform((k, m), 0x72616e67 + rank)
+    lens = [m] * k
+    env.torch.cuda.synchronize(env.dev)
 
     def commit_fn(_polys):
         xy, inf = ctx.commit_device(cshard, sl.data_ptr(), [m], m)
-        return [to_pt(xy[0], inf[0])]
+        return [env.point(xy[0], inf[0])]
 
     def begin_fn():
-        return _native.limbs_to_ints(ctx.open_shard_begin(sl.data_ptr(), [m], m, zw, xw).reshape(1, 4))[0]
+        return nat.limbs_to_ints(ctx.open_shard_begin(sl.data_ptr(), lens, m, zw, xw).reshape(1, 4))[0]
 
     def finish_fn(carry, first):
-        xy, inf, ev = ctx.open_shard_finish(oshard, zw, _native.int_to_words(carry), first)
-        return to_pt(xy, inf[0]), (_native.limbs_to_ints(ev.reshape(1, 4))[0] if first else None)
+        xy, inf, ev = ctx.open_shard_finish(oshard, zw, nat.int_to_words(carry), first)
+        return env.point(xy, inf[0]), (nat.limbs_to_ints(ev.reshape(1, 4))[0] if first else None)
 
     dc = DistributedCommitter(commit_fn, kzg.add, kzg.Z1)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
 
     def step():
         return dc.commit_range(None), dc.open_range(begin_fn, finish_fn, z, r, n)
 
-    for _ in range(args.warmup):
+    for _ in range(2):
         step()
-    barrier()
+    env.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.range_steps):
         commitment, (proof, ev) = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # trapdoor identities, evaluated shard-wise on the devices: p(tau) = sum_g tau^lo_g * slice_g(tau)
-    part = ctx.poly_eval(m, sl.data_ptr(), tau) * pow(tau, lo, r) % r
-    parts = [part]
-    if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, part)
-    p_tau = sum(parts) % r
-    g1 = kzg._g1
-
-    def affine(pt):
-        q = g1.normalize(pt)
-        return (int(q[0]), int(q[1]))
-
-    ok_commit = affine(commitment) == affine(kzg.multiply(kzg.G1, p_tau))
-    q_tau = (xi * p_tau - ev) * pow(tau - z, -1, r) % r               # (P(tau) - P(z)) / (tau - z), P = xi * p
-    ok_open = affine(proof) == affine(kzg.multiply(kzg.G1, q_tau))
-    if rank == 0:
-        print(json.dumps({
-            "metric": "KZG commit + batched open per second, one degree-2^%d polynomial sharded by coefficient range"
-                      % args.log_n,
-            "value": args.steps / elapsed, "unit": "commit+open/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
-            "dtype": "integer: 13x30-bit limbs in u32 (381-bit Fp), 9x29-bit limbs (255-bit Fr), 64-bit multiply-add",
-            "data": "synthetic",
-            "config": {"workload": f"degree-2^{args.log_n} commit + open, {args.curve}, key and polynomial split by "
-                                   f"coefficient range over {world} rank(s)",
-                       "log_n": args.log_n, "curve": args.curve, "coefficients_per_rank": m,
-                       "exchange": "one field element per rank (open) and one G1 point per rank per operation, "
-                                   "all-gathered and added on the host"},
-            "verified": {"commit_trapdoor": bool(ok_commit), "open_trapdoor": bool(ok_open)},
-            "srs_setup_s": t_srs}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0 if (ok_commit and ok_open) else 1
+    env.barrier()
+    elapsed = env.max_over_ranks(time.perf_counter() - t0)
+    # trapdoor identities, evaluated shard-wise on the devices: p_i(tau) = sum_g tau^lo_g * slice_(g,i)(tau)
+    mine = b"".join((ctx.poly_eval(m, sl[i].data_ptr(), tau) * pow(tau, lo, r) % r).to_bytes(32, "little")
+                    for i in range(k))
+    p_tau = [0] * k
+    for blob in all_gather_bytes(mine):
+        for i in range(k):
+            p_tau[i] = (p_tau[i] + int.from_bytes(blob[32 * i:32 * i + 32], "little")) % r
+    ok_commit = env.affine(commitment) == env.g1_times(p_tau[0])
+    P_tau = sum(pow(xi, i + 1, r) * p_tau[i] for i in range(k)) % r
+    ok_open = env.affine(proof) == env.g1_times((P_tau - ev) * pow((tau - z) % r, -1, r))
+    del cshard, oshard, sl
+    out = {
+        "metric": f"KZG commit + open of k = {k} per second, degree-2^{log_n} polynomials sharded by coefficient range",
+        "value": args.range_steps / elapsed, "unit": "commit+open/s", "n_gpus": world, "steps": args.range_steps,
+        "ms_per_step": elapsed / args.range_steps * 1e3, "scaling": "strong",
+        "log_n": log_n, "k": k, "coefficients_per_rank": m,
+        "exchange": "one 32-byte field element per rank (open) and one 97-byte G1 record per rank per operation, "
+                    "all-gathered as uint8 tensors and added on the host",
+        "verified": {"commit_trapdoor": bool(ok_commit), "open_trapdoor": bool(ok_open)},
+        "srs_setup_s": t_srs,
+    }
+    return out, bool(ok_commit and ok_open)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--curve", default="bls12_381")
-    ap.add_argument("--batch", type=int, default=4, help="polynomials per step (one commit call)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-isolated", action="store_true", help="skip the one-commit-at-a-time accumulate timing")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
-                                                      "multi-rank path with all ranks on one GPU)")
-    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--mode", default="batch", choices=("batch", "range"),
-                    help="batch (default, the headline metric): every rank commits its own polynomials; "
-                         "range: ONE degree-2^log_n polynomial and the key sharded by coefficient range over "
-                         "the ranks, commit + batched open per step (BASELINE config 4; strong scaling)")
-    args = ap.parse_args()
+def section_dist_ntt(env):
+    """The four-step transform of 2^log_n elements sharded over the ranks (sharding.DistributedNTT): forward
+    in natural order (three all-to-alls), inverse into the transposed layout (two).  Every rank also runs
+    the whole transform alone and compares its shard."""
+    from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps, transposed_index
+    args, ctx, nat, torch = env.args, env.ctx, env.native, env.torch
+    world, rank = env.world, env.rank
+    log_n = args.range_log_n
+    k1 = (log_n + 1) // 2
+    N1, N2 = 1 << k1, 1 << (log_n - k1)
+    if world & (world - 1) or N1 % world or N2 % world or log_n <= 12:
+        return {"skipped": f"world = {world} must be a power of two dividing 2^{log_n - k1}"}, True
+    n = 1 << log_n
+    r, gen = (R_BLS, 7) if args.curve == "bls12_381" else (R_BN, 5)
+    ww = nat.int_to_words(root_of_unity(r, gen, n))
+    full = env.uniform((n,), 0x646e7474)                 # the same on every rank
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    out = {"log_n": log_n, "n_gpus": world, "backend": args.backend}
+    ok_all = True
+    for name, inverse, layout in (("forward_natural", False, "natural"), ("inverse_transposed", True, "transposed")):
+        d = DistributedNTT(GpuNttOps(ctx, log_n, ww, inverse))
+        for _ in range(2):
+            res = d.transform(full[lo:hi].clone(), log_n, layout=layout)
+        iters = 5
+        xs = [full[lo:hi].clone() for _ in range(iters)]
+        env.barrier()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            res = d.transform(xs[i], log_n, layout=layout)
+        env.barrier()
+        elapsed = env.max_over_ranks(time.perf_counter() - t0)
+        ref = full.clone()
+        ctx.ntt_device(ref.data_ptr(), log_n, ww, inverse, 1)
+        torch.cuda.synchronize(env.dev)
+        if layout == "natural":
+            ok = bool(torch.equal(res, ref[lo:hi]))
+        else:
+            idx = torch.arange(hi - lo, device=env.dev)
+            gidx = (idx % N2) * N1 + rank * (N1 // world) + idx // N2
+            assert int(gidx[1]) == transposed_index(log_n, world, rank, 1)
+            ok = bool(torch.equal(res, ref[gidx]))
+        flag = torch.tensor([1 if ok else 0], device=env.dev if args.backend == "nccl" else "cpu")
+        if world > 1:
+            env.dist.all_reduce(flag, op=env.dist.ReduceOp.MIN)
+        ok = bool(int(flag.item()))
+        ok_all &= ok
+        out[name] = {"ms": elapsed / iters * 1e3, "elements_per_s": n * iters / elapsed,
+                     "all_to_alls": 3 if layout == "natural" else 2, "verified": ok}
+        del xs, ref
+    del full
+    return out, ok_all
 
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        return launch(args, argv)
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: WORLD_SIZE = {world} but --gpus {args.gpus}: the launcher and the label disagree",
+                  file=sys.stderr)
+        return 2
+    if args.rehearse_launch:
+        return rehearse_launch(args, world, rank)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if args.one_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, "
+                         f"{torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -222,10 +504,23 @@ def main():
     # library's kernels are then ordered on one queue
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
+    ctx.bind_torch_stream(stream)
+    env = Env(args, torch, dist, ctx, dev, world, rank, _native)
+
+    def finish(code):
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return code
 
     if args.mode == "range":
-        return run_range(args, ctx, dev, world, rank, dist, torch, _native)
+        out, ok = section_range(env)
+        if rank == 0:
+            out.update({"warmup": 2, "higher_is_better": True, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+                        "config": {"workload": f"degree-2^{args.range_log_n} commit + open of {args.open_k}, {args.curve}, "
+                                               f"key and polynomials split by coefficient range over {world} rank(s)"}})
+            print(json.dumps(out), flush=True)
+        return finish(0 if ok else 1)
 
     r, gen = (R_BLS, 7) if args.curve == "bls12_381" else (R_BN, 5)
     fp_bytes = 48 if args.curve == "bls12_381" else 32
@@ -235,16 +530,13 @@ def main():
     w_words = _native.int_to_words(omega)
 
     # synthetic workload: SRS [tau^i G1] generated on the device; uniform Fr evaluations (seeded per rank)
-    tau = 0x6b7a675f736e61726b7a675f736e6172 % r
+    tau = TAU % r
     t0 = time.perf_counter()
     srs = ctx.srs_generate(_native.int_to_words(tau), n)
     ctx.synchronize()
     t_srs = time.perf_counter() - t0
-    g = torch.Generator(device="cpu").manual_seed(0x6b7a + rank)
     B = args.batch
-    host = torch.randint(0, 1 << 62, (B, n, 4), generator=g, dtype=torch.int64)
-    host[:, :, 3] >>= 3                                    # < 2^253 < r
-    evals = host.to(dev)
+    evals = env.uniform((B, n), 0x6b7a + rank)
     # two work buffers: a step's coefficients stay untouched while its commits are in flight.  A step
     # transforms its buffer in place, so the "evaluations" of step i+2 are the coefficients of step i:
     # an INTT is a bijection on Fr^n, the scalars stay uniform, and no copy sits in the timed region.
@@ -261,41 +553,46 @@ def main():
         results[i] = (out_xy, out_inf)
         ctx.commit_device_async(srs, work.data_ptr(), lens, n, out_xy, out_inf)
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     for i in range(args.warmup):
         step(i)
     ctx.commit_flush()
     ctx.prof_enable(True)
     ctx.prof_reset()
-    barrier()
+    env.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     ctx.commit_flush()                                      # every result is on the host before the clock stops
-    barrier()
+    env.barrier()
     elapsed = time.perf_counter() - t0
-    assert all(int(inf.sum()) == 0 and xy.any() for xy, inf in results.values())
     ctx.prof_enable(False)
+    elapsed = env.max_over_ranks(elapsed)
+    spans_main = {name: ctx.prof_read(name) for name in
+                  ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
+
+    # ---- the timed loop's own results, checked (outside the timed region): the coefficients of the last
+    # step are still in its work buffer; commit(ck, p) must be p(tau) G1 for each of its B polynomials,
+    # and no earlier step may have produced infinity or the zero record
+    last = args.steps - 1
+    ok_headline = all(int(inf.sum()) == 0 and xy.any(axis=1).all() for xy, inf in results.values())
+    if args.steps > 0:
+        xy_last, inf_last = results[last]
+        for p in range(B):
+            p_tau = ctx.poly_eval(n, works[last & 1][p].data_ptr(), tau)
+            ok_headline &= (not inf_last[p]) and env.affine(env.point(xy_last[p])) == env.g1_times(p_tau)
+    flag = torch.tensor([1 if ok_headline else 0], device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    ok_headline = bool(int(flag.item()))
 
     # The NTT half of the metric, timed alone (inside the pipelined loop above its kernels share the
     # GPU with the previous polynomial's bucket reduction, which inflates their event times).
-    spans_main = {name: ctx.prof_read(name) for name in
-                  ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
     ctx.prof_enable(True)
     ctx.prof_reset()
     ntt_iters = max(args.steps, 10)
     for i in range(ntt_iters):
         ctx.ntt_device(works[0].data_ptr(), log_n, w_words, bool(i & 1) ^ True, B)
-    barrier()
+    env.barrier()
     ntt_alone = ctx.prof_read("ntt_pass")
     # The accumulate kernel alone: in the pipelined loop it deliberately shares every SIMD with the
     # next polynomial's prep and the previous one's reduce stage, so its span there is the pipeline
@@ -306,9 +603,22 @@ def main():
         inf1 = np.zeros(1, dtype=np.uint8)
         ctx.commit_device_async(srs, works[0].data_ptr() + p * n * 32, [n], n, xy1, inf1)
         ctx.commit_flush()
-    barrier()
+    env.barrier()
     acc_alone = ctx.prof_read("msm_accumulate")
     ctx.prof_enable(False)
+
+    sections, ok_sections = {}, True
+    if args.mode == "all" and not args.no_open:
+        sections["open"], ok = section_open(env, srs, n)
+        ok_sections &= ok
+    del srs, works, evals
+    torch.cuda.empty_cache()
+    if args.mode == "all" and not args.no_range:
+        sections["range_mode"], ok = section_range(env)
+        ok_sections &= ok
+    if args.mode == "all" and world > 1 and not args.no_dist_ntt:
+        sections["distributed_ntt"], ok = section_dist_ntt(env)
+        ok_sections &= ok
 
     spans = dict(spans_main)
     spans["ntt_pass"] = (ntt_alone[0] * args.steps / ntt_iters, ntt_alone[1] * args.steps // ntt_iters)
@@ -320,6 +630,7 @@ def main():
         # one launch covers the whole batch; two launches (passes) per transform above 2^12
         ntt_per_transform_s = (ntt_ms / max(ntt_cnt, 1)) * (2e-3 if log_n > 12 else 1e-3) / B
         ntt_bytes = 2 * n * 32                              # read + write every element once
+        acc_alone_s = acc_alone[0] / max(acc_alone[1], 1) * 1e-3
         out = {
             "metric": "KZG G1 commits/sec (INTT 2^%d + commit 2^%d, BLS12-381)" % (log_n, log_n)
             if args.curve == "bls12_381" else "KZG G1 commits/sec (INTT + commit, BN254)",
@@ -332,12 +643,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "integer: 13x30-bit limbs in u32 (381-bit Fp), 9x29-bit limbs (255-bit Fr), 64-bit multiply-add",
+            "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": f"degree-2^{log_n} INTT + KZG commit, {args.curve}, 2^{log_n}-point SRS, "
                                    f"uniform Fr scalars, batch of {B} polynomials per GPU per step",
                        "log_n": log_n, "curve": args.curve, "batch": B, "window_bits": 20 if n >= (1 << 18) else 16,
                        "sharding": "independent polynomials per rank, replicated SRS"},
+            "verified": {"last_step_commit_trapdoor": ok_headline},
             "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
             "ntt_ms": ntt_per_transform_s * 1e3,
             "kernel_ms_per_commit": {k: (v[0] / (args.steps * B)) for k, v in spans.items()},
@@ -353,13 +665,13 @@ def main():
                 "algorithmic_bytes_per_launch": msm_bytes,
                 "avg_launch_ms": acc_avg_s * 1e3,
                 "isolated": {   # same kernel with nothing else on the GPU (one commit at a time)
-                    "avg_launch_ms": acc_alone[0] / max(acc_alone[1], 1),
-                    "achieved": msm_bytes / (acc_alone[0] / max(acc_alone[1], 1) * 1e-3) / 1e9 if acc_alone[0] > 0 else None,
-                    "frac": msm_bytes / (acc_alone[0] / max(acc_alone[1], 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS
-                    if acc_alone[0] > 0 else None,
+                    "avg_launch_ms": acc_alone_s * 1e3,
+                    "achieved": msm_bytes / acc_alone_s / 1e9 if acc_alone_s > 0 else None,
+                    "frac": msm_bytes / acc_alone_s / 1e9 / HBM_PEAK_GBPS if acc_alone_s > 0 else None,
                 },
                 "note": "in the timed loop the persistent accumulate kernel runs beside prep(p+1) and reduce(p-1); "
-                        "its span there is the pipeline period",
+                        "its span there is the pipeline period.  The kernel is VALU-issue bound, not HBM bound: see "
+                        "`limiter`",
             },
             "roofline_ntt": {
                 "kernel": "ntt_pass_kernel (2 launches per transform)",
@@ -372,17 +684,33 @@ def main():
                 "algorithmic_bytes_per_transform": ntt_bytes,
             },
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):                   # HBM bytes per launch from rocprofv3 --pmc passes
-            tr = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = tr.get("msm_accumulate_kernel")
-            out["roofline_ntt"]["traffic"] = tr.get("ntt_pass_kernel_per_transform")
+        counters_file = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(counters_file):
+            # rocprofv3 --pmc passes of this build (tools/profile_bench.sh -> tools/summarize_profile.py):
+            # HBM bytes per launch (FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied) and VALU
+            # wave-instructions per launch.  The second object names the limiter the counters show.
+            cj = json.load(open(counters_file))
+            for key, kern, dur_s in (("roofline", "msm_accumulate_kernel", acc_alone_s),
+                                     ("roofline_ntt", "ntt_pass_kernel_per_transform", ntt_per_transform_s)):
+                ent = cj.get(kern) or {}
+                out[key]["traffic"] = ent.get("hbm_bytes")
+                if ent.get("valu_wave_instructions") and dur_s > 0:
+                    ach = ent["valu_wave_instructions"] / dur_s / 1e9
+                    out[key]["limiter"] = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINSTR,
+                                           "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GINSTR,
+                                           "valu_wave_instructions_per_launch": ent["valu_wave_instructions"],
+                                           "hbm_achieved_GBps_from_traffic": (ent["hbm_bytes"] / dur_s / 1e9)
+                                           if ent.get("hbm_bytes") else None,
+                                           "source": cj.get("source")}
+        out.update(sections)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.curve, log_n, r, omega)
+            out["cpu_baseline"] = cpu_baseline(args.curve, log_n, omega)
+            out["cpu_baseline_optimised"] = cpu_baseline_optimised(args.curve, log_n, omega)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ok_all = ok_headline and ok_sections
+    if not ok_all and rank == 0:
+        print("bench.py: a result failed verification (see the `verified` flags)", file=sys.stderr)
+    return finish(0 if ok_all else 1)
 
 
 if __name__ == "__main__":

@@ -186,6 +186,12 @@ class DistributedNTT:
             return self._exchange(send)
         if self.world == 1:
             return send
+        if send.is_cuda and dist.get_backend(self.group) != "nccl":
+            # rehearsal on one GPU: gloo moves host memory only
+            host = send.cpu()
+            got = torch.empty_like(host)
+            dist.all_to_all_single(got, host, group=self.group)
+            return got.to(send.device)
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
         return recv

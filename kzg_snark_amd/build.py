@@ -11,7 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+# KZG_BUILD_DIR: build a variant elsewhere (A/B timing, with KZG_EXTRA_HIPCC_FLAGS and KZG_MI355X_LIB)
+LIBDIR = os.environ.get("KZG_BUILD_DIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libkzg_mi355x.so")
 SOURCES = ["api.hip", "ntt.hip", "msm.hip", "msm_prep.hip", "poly.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -38,6 +38,9 @@
 
 namespace kzg {
 
+// c + a*b: one v_mad_u64_u32
+static KZG_HD uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+
 template <class F>
 struct Fe {
   uint32_t l[F::N];
@@ -123,110 +126,122 @@ struct Field {
     }
   }
 
-  // Montgomery product a*b/R.  See the header comment for input bounds.
+  // ---- multiplication: product scanning (column by column) --------------------------------------
+  // Every simple integer instruction of gfx950 issues at the rate of v_mad_u64_u32 (measured,
+  // tools/microbench/int_rates.hip), so what counts is the NUMBER of instructions.  Column k of the
+  // Montgomery product collects  sum_(i+j=k) a_i b_j + sum_(i+j=k) m_i p_j  on top of the carry of
+  // column k-1: the carry is the initial value of the column's multiply-add chain (no separate
+  // 64-bit addition per column), the low half of the columns yields the quotient digits m_k, the
+  // high half the result limbs.  (hipcc re-associates each column's sum so that the incoming carry is
+  // added last -- one v_lshl_add_u64 per column remains; forcing a single chain with inline-asm
+  // multiply-adds was worth another 0.4 % and was not kept)
+  //
+  // Column capacity: products of two L-bit limbs are < 2^(2L); a 64-bit column holds CAP of them
+  // next to the carry.  Columns with more products (L = 30, N = 13: the 11 middle ones) are split:
+  // the partial sum is cut into its low L bits (which stay in the chain) and its upper part (added
+  // to the outgoing carry).  `UA` = how many units one a*b product may take (operands with limbs
+  // up to 2^(L+1) from add_lazy count 2 or 4).
+  template <int UNITS_AB = 1>
   static KZG_HD E mul(const E& a, const E& b) {
-    uint64_t w[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) w[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const uint32_t bi = b.l[i];
-#pragma unroll
-      for (int j = 0; j < N; ++j) w[j] += (uint64_t)a.l[j] * bi;
-      const uint32_t m = ((uint32_t)w[0] * F::N0) & MASK;
-#pragma unroll
-      for (int j = 0; j < N; ++j) w[j] += (uint64_t)m * F::P[j];
-      // low L bits of w[0] are now zero: divide by 2^L and slide the window
-      const uint64_t c = w[0] >> L;
-#pragma unroll
-      for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
-      w[N - 1] = 0;
-      w[0] += c;
-      constexpr int ROWS = CAP / 2;
-      if (ROWS < N && (i + 1) % ROWS == 0 && i + 1 < N) normalize_cols(w);
-    }
+    uint32_t m[N];
     E r;
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N - 1; ++j) {
-      const uint64_t t = w[j] + c;
-      r.l[j] = (uint32_t)t & MASK;
-      c = t >> L;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+      const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+      const int nab = hi - lo + 1;                       // a*b products of this column
+      const int nmp = k < N ? k + 1 : nab;               // m*p products (incl. m_k p_0 in the low half)
+      const bool split = nab * UNITS_AB + nmp > CAP - 1;
+      uint64_t upper = 0;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) acc = mad_wide(a.l[i], b.l[k - i], acc);
+      if (split) { upper = acc >> L; acc &= (uint64_t)MASK; }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (i < k || k >= N) acc = mad_wide(m[i], F::P[k - i], acc);
+      if (k < N) {
+        m[k] = ((uint32_t)acc * F::N0) & MASK;
+        acc = mad_wide(m[k], F::P[0], acc);
+      } else {
+        r.l[k - N] = (uint32_t)acc & MASK;
+      }
+      acc >>= L;
+      if (split) acc += upper;
     }
-    r.l[N - 1] = (uint32_t)(w[N - 1] + c);
+    r.l[N - 1] = (uint32_t)acc;
     return r;
   }
-  // Montgomery square: the off-diagonal products are computed once against the doubled
-  // operand (N(N+1)/2 + N^2 multiply-adds instead of 2N^2).
+  // Montgomery square: off-diagonal products once, against the doubled operand.
   static KZG_HD E sqr(const E& a) {
-    uint64_t t[2 * N];
-    uint32_t a2[N];
+    uint32_t m[N], a2[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) a2[j] = a.l[j] << 1;
-#pragma unroll
-    for (int k = 0; k < 2 * N; ++k) t[k] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      t[2 * i] += (uint64_t)a.l[i] * a.l[i];
-#pragma unroll
-      for (int j = i + 1; j < N; ++j) t[i + j] += (uint64_t)a.l[i] * a2[j];
-    }
-    // product columns hold up to N product-equivalents (doubled terms count twice); the
-    // reduction adds up to N more
-    if (2 * N > CAP) normalize_cols(t);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const uint32_t m = ((uint32_t)t[i] * F::N0) & MASK;
-#pragma unroll
-      for (int j = 0; j < N; ++j) t[i + j] += (uint64_t)m * F::P[j];
-      t[i + 1] += t[i] >> L;
-    }
     E r;
-    uint64_t c = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N - 1; ++j) {
-      const uint64_t v = t[N + j] + c;
-      r.l[j] = (uint32_t)v & MASK;
-      c = v >> L;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+      const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+      const int nab = hi - lo + 1;                       // units: a doubled product counts twice
+      const int nmp = k < N ? k + 1 : nab;
+      const bool split = nab + nmp > CAP - 1;
+      uint64_t upper = 0;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) {
+        const int j = k - i;
+        if (i < j) acc = mad_wide(a.l[i], a2[j], acc);
+        else if (i == j) acc = mad_wide(a.l[i], a.l[i], acc);
+      }
+      if (split) { upper = acc >> L; acc &= (uint64_t)MASK; }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (i < k || k >= N) acc = mad_wide(m[i], F::P[k - i], acc);
+      if (k < N) {
+        m[k] = ((uint32_t)acc * F::N0) & MASK;
+        acc = mad_wide(m[k], F::P[0], acc);
+      } else {
+        r.l[k - N] = (uint32_t)acc & MASK;
+      }
+      acc >>= L;
+      if (split) acc += upper;
     }
-    r.l[N - 1] = (uint32_t)(t[2 * N - 1] + c);
+    r.l[N - 1] = (uint32_t)acc;
     return r;
   }
 
   // a*b + c*d with ONE Montgomery reduction (weak-normal in and out: (4p^2+4p^2)/R + p < 2p
-  // needs 8p < R, true for all four fields).  Columns hold 2N products + N reduction products.
+  // needs 8p < R, true for all four fields).
   static KZG_HD E mul2(const E& a, const E& b, const E& c, const E& d) {
     static_assert(F::BITS + 3 <= L * N, "mul2 needs 8p < R");
-    uint64_t w[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) w[j] = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const uint32_t bi = b.l[i], di = d.l[i];
-#pragma unroll
-      for (int j = 0; j < N; ++j) w[j] += (uint64_t)a.l[j] * bi;
-#pragma unroll
-      for (int j = 0; j < N; ++j) w[j] += (uint64_t)c.l[j] * di;
-      const uint32_t m = ((uint32_t)w[0] * F::N0) & MASK;
-#pragma unroll
-      for (int j = 0; j < N; ++j) w[j] += (uint64_t)m * F::P[j];
-      const uint64_t cy = w[0] >> L;
-#pragma unroll
-      for (int j = 0; j < N - 1; ++j) w[j] = w[j + 1];
-      w[N - 1] = 0;
-      w[0] += cy;
-      constexpr int ROWS = CAP / 3;          // three products per column per row
-      if (ROWS < N && (i + 1) % ROWS == 0 && i + 1 < N) normalize_cols(w);
-    }
+    uint32_t m[N];
     E r;
-    uint64_t cy = 0;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < N - 1; ++j) {
-      const uint64_t t = w[j] + cy;
-      r.l[j] = (uint32_t)t & MASK;
-      cy = t >> L;
+    for (int k = 0; k < 2 * N - 1; ++k) {
+      const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+      const int nab = hi - lo + 1;
+      const int nmp = k < N ? k + 1 : nab;
+      const bool split1 = 2 * nab > CAP - 1;             // between a*b and c*d
+      const bool split2 = (split1 ? nab : 2 * nab) + nmp > CAP - 1;   // before m*p
+      uint64_t upper = 0;
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) acc = mad_wide(a.l[i], b.l[k - i], acc);
+      if (split1) { upper = acc >> L; acc &= (uint64_t)MASK; }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) acc = mad_wide(c.l[i], d.l[k - i], acc);
+      if (split2) { upper += acc >> L; acc &= (uint64_t)MASK; }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (i < k || k >= N) acc = mad_wide(m[i], F::P[k - i], acc);
+      if (k < N) {
+        m[k] = ((uint32_t)acc * F::N0) & MASK;
+        acc = mad_wide(m[k], F::P[0], acc);
+      } else {
+        r.l[k - N] = (uint32_t)acc & MASK;
+      }
+      acc >>= L;
+      if (split1 || split2) acc += upper;
     }
-    r.l[N - 1] = (uint32_t)(w[N - 1] + cy);
+    r.l[N - 1] = (uint32_t)acc;
     return r;
   }
 

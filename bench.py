@@ -605,6 +605,8 @@ def main(argv=None):
         ctx.commit_flush()
     env.barrier()
     acc_alone = ctx.prof_read("msm_accumulate")
+    spans_alone = {name: ctx.prof_read(name) for name in
+                   ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
     ctx.prof_enable(False)
 
     sections, ok_sections = {}, True
@@ -653,6 +655,8 @@ def main(argv=None):
             "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
             "ntt_ms": ntt_per_transform_s * 1e3,
             "kernel_ms_per_commit": {k: (v[0] / (args.steps * B)) for k, v in spans.items()},
+            # the same spans with ONE commit in flight (nothing else on the GPU): each stage's own duration
+            "kernel_ms_per_commit_isolated": {k: (v[0] / max(v[1], 1)) for k, v in spans_alone.items()},
             "srs_setup_s": t_srs,
             "roofline": {
                 "kernel": "msm_accumulate_kernel",

@@ -65,7 +65,9 @@ void kzg_ctx_destroy(kzg_ctx* ctx);
 const char* kzg_last_error(const kzg_ctx* ctx);
 
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work of this context.
- * NULL restores the context's own stream. */
+ * NULL restores the context's own (non-blocking) stream; to run on HIP's null stream -- torch's
+ * default stream -- pass hipStreamLegacy.  A context that keeps its own stream is NOT ordered with
+ * work the caller enqueues elsewhere: synchronise, or bind the producer's stream. */
 int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream);
 /* Block until everything enqueued on the context's stream has finished. */
 int kzg_ctx_synchronize(kzg_ctx* ctx);

@@ -21,6 +21,7 @@ KZG_CURVE_BN254 = 0
 KZG_CURVE_BLS12_381 = 1
 CURVE_IDS = {"bn254": KZG_CURVE_BN254, "bls12_381": KZG_CURVE_BLS12_381}
 
+HIP_STREAM_LEGACY = 1          # hipStreamLegacy: the explicit handle of HIP's null stream (hip_runtime_api.h)
 KZG_ERR_DEGREE = -4
 KZG_ERR_NODEV = -3
 
@@ -187,7 +188,9 @@ class Context:
         import torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
-        self.set_stream(stream.cuda_stream)
+        # torch's default stream is HIP's null stream (handle 0), and a NULL handle means "back to the
+        # context's own stream" in kzg_ctx_set_stream: name the null stream explicitly instead
+        self.set_stream(stream.cuda_stream or HIP_STREAM_LEGACY)
         self._torch_stream = stream            # keep the handle alive as long as it is bound
         return stream
 

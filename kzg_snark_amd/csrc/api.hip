@@ -128,7 +128,9 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
       KZG_HIP(c, hipStreamSynchronize(c->stream));
       KZG_HIP(c, hipStreamDestroy(c->stream));
     }
-    c->stream = static_cast<hipStream_t>(hip_stream);
+    // hipStreamLegacy names HIP's null stream (torch's default stream).  Internally that is the plain
+    // null handle, which every runtime entry point accepts (event record / wait on the alias do not).
+    c->stream = hip_stream == static_cast<void*>(hipStreamLegacy) ? nullptr : static_cast<hipStream_t>(hip_stream);
     c->own_stream = false;
   } else if (!c->own_stream) {
     KZG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

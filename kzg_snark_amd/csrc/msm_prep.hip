@@ -46,10 +46,13 @@ constexpr uint32_t TPB = 256;     // threads per workgroup, every kernel here
 #define KZG_PREP_PRIO 3
 #endif
 #ifndef KZG_PREP_CH1
-#define KZG_PREP_CH1 1024
+#define KZG_PREP_CH1 4096
 #endif
 constexpr uint32_t CH1 = KZG_PREP_CH1;    // scalars per partition-1 chunk
-constexpr uint32_t CH2 = 8192;    // entries per partition-2 chunk
+#ifndef KZG_PREP_CH2
+#define KZG_PREP_CH2 8192
+#endif
+constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
 constexpr uint32_t NCLS = 256;    // length classes
 
@@ -171,9 +174,10 @@ __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scal
   using P = PW<WB>;
   side_priority();
   __shared__ uint32_t cur[P::NBIN];
-  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + blockIdx.x];
+  const uint32_t chunk = blockIdx.x;
+  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + chunk];
   __syncthreads();
-  const uint32_t base = blockIdx.x * CH1;
+  const uint32_t base = chunk * CH1;
   for (uint32_t it = 0; it < CH1 / TPB; ++it) {
     const uint32_t i = base + it * TPB + threadIdx.x;
     if (i < n)

@@ -387,3 +387,65 @@ def test_skewed_scalars_2_20(native, kzgs):
         xy, inf = ctx.commit(ck.srs, sc.reshape(1, n, 4), [n], n)
         coeffs = [int(v) << shift for v in vals]
         assert tuple(native.limbs_to_ints(xy.reshape(2, 6))) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+
+
+def test_pipelined_commit_across_calls_with_buffer_reuse(native, kzgs):
+    """kzg_commit_device_async / kzg_commit_flush -- the path bench.py's headline loop times: more
+    polynomials than the pipeline has slots, issued over several calls, and the SAME scalar buffer
+    overwritten between the calls by work on the context's stream (legal: the call makes the
+    stream wait until prep has consumed the scalars; include/kzg_mi355x.h).  Every result against
+    the trapdoor identity, so a slot-recycling or stream-ordering regression cannot hide."""
+    import torch
+    cv = O.BLS12_381
+    kzg = kzgs["bls12_381"]
+    ctx = native.Context("bls12_381")
+    stream = torch.cuda.Stream(device="cuda:0")
+    ctx.bind_torch_stream(stream)
+    n = (1 << 18) + 3                         # 20-bit windows, not a power of two
+    tau = 0x5151515151515151515151 % cv.r
+    srs = ctx.srs_generate(native.int_to_words(tau), n)
+    lens = [n, n - 5, n // 2]
+    rounds, L = 4, ctx.fp_limbs               # 12 polynomials through 4 slots
+    g = torch.Generator(device="cuda:0").manual_seed(77)
+    outs, want = [], []
+    with torch.cuda.stream(stream):
+        buf = torch.zeros((len(lens), n, 4), dtype=torch.int64, device="cuda:0")
+        for _ in range(rounds):
+            fresh = torch.randint(0, 1 << 62, (len(lens), n, 4), generator=g, dtype=torch.int64, device="cuda:0")
+            fresh[..., 3] >>= 3
+            buf.copy_(fresh)                  # overwrites the scalars of the previous call on the context's stream
+            want.append([ctx.poly_eval(m, fresh[i].data_ptr(), tau) for i, m in enumerate(lens)])
+            xy = np.zeros((len(lens), 2 * L), dtype=np.uint64)
+            inf = np.zeros(len(lens), dtype=np.uint8)
+            outs.append((xy, inf))
+            ctx.commit_device_async(srs, buf.data_ptr(), lens, n, xy, inf)
+        ctx.commit_flush()
+    G1 = O.from_affine(cv.g1)
+    for (xy, inf), evs in zip(outs, want):
+        for i, p_tau in enumerate(evs):
+            assert inf[i] == 0
+            assert tuple(native.limbs_to_ints(xy[i].reshape(2, L))) == O.normalize(O.multiply(G1, p_tau, cv), cv)
+    ctx.close()
+
+
+def test_bind_torch_stream_orders_the_default_stream(native):
+    """Context.bind_torch_stream() with torch's DEFAULT stream (HIP's null stream, handle 0 -- which
+    kzg_ctx_set_stream would read as "back to the private stream"): a torch copy followed at once
+    by an engine call must see the copied data, and the commit path must accept that stream."""
+    import torch
+    ctx = native.Context("bls12_381")
+    bound = ctx.bind_torch_stream()
+    assert bound.cuda_stream == torch.cuda.default_stream().cuda_stream
+    n = 1 << 21
+    base = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device="cuda:0")
+    base[:, 3] >>= 3
+    torch.cuda.synchronize()
+    for it in range(8):
+        sl = base[it:it + 2 * n:2].contiguous()              # strided copy on the default stream
+        got = ctx.poly_eval(n, sl.data_ptr(), 12345)          # read at once by the engine
+        torch.cuda.synchronize()
+        assert got == ctx.poly_eval(n, sl.data_ptr(), 12345)
+    srs = ctx.srs_generate(native.int_to_words(7), 1 << 10)
+    xy, inf = ctx.commit_device(srs, base.data_ptr(), [1 << 10], 1 << 10)     # events / waits on the null stream
+    assert inf[0] == 0
+    ctx.close()

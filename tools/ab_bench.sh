@@ -8,7 +8,9 @@ import json, sys
 v = sys.argv[1]
 try:
     d = json.loads(open(f"gpurun_out/ab_{v}.json").read().strip().splitlines()[-1])
-    print(f"{v:14s} {d['value']:7.1f} commits/s  acc pipelined {d['kernel_ms_per_commit']['msm_accumulate']:.3f} ms  alone {d['roofline']['isolated']['avg_launch_ms']:.3f} ms  ntt {d['ntt_ms']*1e3:.1f} us  verified {d['verified']}")
+    iso = d.get("kernel_ms_per_commit_isolated", {})
+    print(f"{v:14s} {d['value']:7.1f} commits/s  acc pipelined {d['kernel_ms_per_commit']['msm_accumulate']:.3f} ms  alone {d['roofline']['isolated']['avg_launch_ms']:.3f} ms  ntt {d['ntt_ms']*1e3:.1f} us  "
+          f"alone: p1 {iso.get('msm_partition1', 0):.3f} p2 {iso.get('msm_partition2', 0):.3f} order {iso.get('msm_order', 0):.3f} fin {iso.get('msm_finalize', 0):.3f} red {iso.get('msm_reduce', 0):.3f}  ok {d['verified']['last_step_commit_trapdoor']}")
 except Exception as e:
     print(v, "no result", e)
 PY

@@ -19,7 +19,8 @@
 //     scatter2    table indices to their bucket
 //   order         buckets by length class (255 - min(len, 255): longest first), the same
 //                 count / row_scan / scatter scheme with 256 classes; slices of <= SEG entries
-//                 per bucket and their exclusive scan (slice_off); arms the work counter.
+//                 per bucket and their exclusive scan (slice_off, two-level, same kernels); arms
+//                 the work counter.  No library call anywhere in the stage.
 //
 // Entries of one bucket land in no fixed order (LDS atomics hand out the ranks).  The group law
 // in ec.h is exact for every case, so the bucket sum - and the affine result - does not depend on it.
@@ -28,7 +29,6 @@
 #include <algorithm>
 #include "internal.h"
 #include "msm_prep.h"
-#include <rocprim/rocprim.hpp>
 
 namespace kzg {
 namespace {
@@ -321,17 +321,38 @@ __global__ __launch_bounds__(TPB) void prep_lscatter_kernel(const uint32_t* bsta
   }
 }
 
-// ns[r] = slices of the r-th bucket in length order; ns[NB] = 0 (so the scan yields the total);
+// slice_off = exclusive scan of ns over the NB + 1 ranks (ns[r] = slices of the r-th bucket in length
+// order, ns[NB] = 0 so that slice_off[NB] is the total), in three launches of this file's own kernels:
+//   ns_totals   per block of TPB ranks: the block's number of slices
+//   row_scan    one workgroup: exclusive prefix over the block totals (prep_row_scan_kernel, one row)
+//   slice_off   per block: ns again, scanned inside the block, plus the block's prefix
+template <int WB>
+__device__ __forceinline__ uint32_t slices_of_rank(const uint32_t* bstart, const uint32_t* order, uint32_t seg, uint32_t r) {
+  if (r >= PW<WB>::NB) return 0u;
+  const uint32_t k = order[r];
+  return (bstart[k + 1] - bstart[k] + seg - 1) / seg;
+}
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_ns_totals_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t seg,
+                                                             uint32_t* blk_total) {
+  side_priority();
+  __shared__ uint32_t sh[TPB];
+  const uint32_t v = slices_of_rank<WB>(bstart, order, seg, blockIdx.x * TPB + threadIdx.x);
+  block_inclusive_scan(v, sh);
+  if (threadIdx.x == 0) blk_total[blockIdx.x] = sh[TPB - 1];
+}
 // also arms the accumulate kernel's work counter
 template <int WB>
-__global__ __launch_bounds__(TPB) void prep_ns_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t seg,
-                                                      uint32_t* ns, uint32_t* chunk_counter) {
+__global__ __launch_bounds__(TPB) void prep_slice_off_kernel(const uint32_t* bstart, const uint32_t* order, uint32_t seg,
+                                                             const uint32_t* blk_prefix, uint32_t* slice_off,
+                                                             uint32_t* chunk_counter) {
   side_priority();
+  __shared__ uint32_t sh[TPB];
   const uint32_t r = blockIdx.x * TPB + threadIdx.x;
-  if (r > PW<WB>::NB) return;
-  if (r == PW<WB>::NB) { ns[r] = 0; *chunk_counter = 0; return; }
-  const uint32_t k = order[r];
-  ns[r] = (bstart[k + 1] - bstart[k] + seg - 1) / seg;
+  const uint32_t v = slices_of_rank<WB>(bstart, order, seg, r);
+  const uint32_t incl = block_inclusive_scan(v, sh);
+  if (r <= PW<WB>::NB) slice_off[r] = blk_prefix[blockIdx.x] + incl - v;
+  if (r == 0) *chunk_counter = 0;
 }
 
 // chunk_rank[c] = rank (position in length order) of the bucket that owns slice 64*c, the first slice
@@ -363,7 +384,7 @@ struct Layout {
   using P = PW<WB>;
   uint32_t m, nchunk1, nchunk2_max, nchunkl;
   size_t off_ent, off_hist1, off_bin_total, off_bin_start, off_chunk_base, off_seg_of_chunk, off_nchunk2, off_hist2,
-      off_histl, off_class_total, off_class_start, off_ns, off_scan_tmp, scan_tmp_bytes, total;
+      off_histl, off_class_total, off_class_start, off_ns, total;
   explicit Layout(uint32_t n) {
     m = n * (uint32_t)P::NWIN;
     nchunk1 = (n + CH1 - 1) / CH1;
@@ -382,12 +403,7 @@ struct Layout {
     off_histl = take((size_t)NCLS * nchunkl * 4);
     off_class_total = take(NCLS * 4);
     off_class_start = take(NCLS * 4);
-    off_ns = take((size_t)(P::NB + 2) * 4);
-    scan_tmp_bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)P::NB + 1,
-                            rocprim::plus<uint32_t>(), nullptr);
-    scan_tmp_bytes = std::max(scan_tmp_bytes, (size_t)16);
-    off_scan_tmp = take(scan_tmp_bytes);
+    off_ns = take((size_t)((P::NB + 1 + TPB - 1) / TPB + 2) * 4);      // block totals of the slice counts (+ their sum)
     total = t;
   }
 };
@@ -437,11 +453,11 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
     hipLaunchKernelGGL(prep_classes_kernel, dim3(1), dim3(TPB), 0, sp, class_total, class_start);
     hipLaunchKernelGGL(prep_lscatter_kernel<WB>, dim3(L.nchunkl), dim3(TPB), 0, sp, bstart, L.nchunkl, histl,
                        class_start, order);
-    hipLaunchKernelGGL(prep_ns_kernel<WB>, dim3((P::NB + 1 + TPB - 1) / TPB), dim3(TPB), 0, sp, bstart, order, seg, ns,
+    const uint32_t nblk = (P::NB + 1 + TPB - 1) / TPB;
+    hipLaunchKernelGGL(prep_ns_totals_kernel<WB>, dim3(nblk), dim3(TPB), 0, sp, bstart, order, seg, ns);
+    hipLaunchKernelGGL(prep_row_scan_kernel, dim3(1), dim3(TPB), 0, sp, ns, nblk, ns + nblk);
+    hipLaunchKernelGGL(prep_slice_off_kernel<WB>, dim3(nblk), dim3(TPB), 0, sp, bstart, order, seg, ns, slice_off,
                        chunk_counter);
-    size_t tb = L.scan_tmp_bytes;
-    KZG_HIP(c, rocprim::exclusive_scan(w + L.off_scan_tmp, tb, ns, slice_off, 0u, (size_t)P::NB + 1,
-                                       rocprim::plus<uint32_t>(), sp));
     hipLaunchKernelGGL(prep_chunk_rank_kernel<WB>, dim3((nchunk_max + TPB - 1) / TPB), dim3(TPB), 0, sp, slice_off,
                        nchunk_max, chunk_rank);
   }

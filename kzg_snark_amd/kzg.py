@@ -84,7 +84,7 @@ class KZG:
         self.R = PolynomialRing(self.Fq, "X")
         self.X = self.R.gen()
         self._ctx = None
-        self._loaded = {}          # id(list ck) -> (CommitmentKey, fingerprint)
+        self._loaded = {}          # id(list ck) -> (CommitmentKey, fingerprint); at most _KEY_CACHE entries, LRU
 
     # ---- py_ecc-shaped single-point operations (host; used by the verifiers) ------
     def _grp(self, pt):
@@ -113,14 +113,28 @@ class KZG:
             self._ctx = _native.get_context(self.curve_type)
         return self._ctx
 
+    _KEY_CACHE = 2                 # device tables kept for list-form keys (a 2^20-point table is 1.7 GiB)
+
+    @staticmethod
+    def _fingerprint(ck):
+        """Length plus up to 16 sampled points: guards the id()-keyed cache against a recycled id
+        and against in-place edits of the list (not a hash of every point: that would cost as much
+        as the upload the cache avoids)."""
+        n = len(ck)
+        if n == 0:
+            return (0,)
+        step = max(1, n // 15)
+        return (n,) + tuple(tuple(int(c) for c in ck[i]) for i in sorted({*range(0, n, step), n - 1}))
+
     def _key(self, ck):
         """Device handle for a commitment key given as CommitmentKey or as a plain
         sequence of point tuples (what the reference's callers hold)."""
         if isinstance(ck, CommitmentKey):
             return ck
-        fp = (len(ck), tuple(ck[0]), tuple(ck[-1])) if len(ck) else (0,)
+        fp = self._fingerprint(ck)
         hit = self._loaded.get(id(ck))
         if hit and hit[1] == fp:
+            self._loaded[id(ck)] = self._loaded.pop(id(ck))       # most recently used last
             return hit[0]
         ctx = self._context()
         L = ctx.fp_limbs
@@ -135,6 +149,11 @@ class KZG:
             coords.append(y)
         xy = _native.ints_to_limbs(coords, L).reshape(n, 2 * L)
         key = CommitmentKey(ctx, ctx.srs_load_g1(np.ascontiguousarray(xy), inf))
+        self._loaded.pop(id(ck), None)
+        while len(self._loaded) >= self._KEY_CACHE:                # evict the least recently used table
+            _, (old, _) = next(iter(self._loaded.items()))
+            del self._loaded[next(iter(self._loaded))]
+            old.srs.close()
         self._loaded[id(ck)] = (key, fp)
         return key
 

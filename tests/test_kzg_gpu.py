@@ -449,3 +449,24 @@ def test_bind_torch_stream_orders_the_default_stream(native):
     xy, inf = ctx.commit_device(srs, base.data_ptr(), [1 << 10], 1 << 10)     # events / waits on the null stream
     assert inf[0] == 0
     ctx.close()
+
+
+def test_list_form_key_cache_is_bounded_and_notices_edits(kzgs):
+    """KZG._key: list-form commitment keys (what the reference's callers pass on every call, kzg.py:80)
+    are uploaded once and cached by id(); the cache holds at most two device tables, frees the evicted
+    one, and a list edited in place is uploaded again instead of silently reusing the old table."""
+    kzg = kzgs["bn254"]
+    ck0, _ = kzg.setup(15, tau=11)
+    lists = [[ck0[i] for i in range(16)] for _ in range(3)]
+    poly = list(range(1, 17))
+    want = kzg.commit(ck0, [poly])
+    for lst in lists:
+        assert kzg.commit(lst, [poly]) == want
+    assert len(kzg._loaded) == kzg._KEY_CACHE and id(lists[0]) not in kzg._loaded
+    first = kzg._loaded[id(lists[2])][0]
+    assert kzg.commit(lists[2], [poly]) == want and kzg._loaded[id(lists[2])][0] is first     # cache hit
+    lists[2][5] = kzg.multiply(kzg.G1, 12345)                                                   # in-place edit
+    got = kzg.commit(lists[2], [poly])
+    assert got != want and kzg._loaded[id(lists[2])][0] is not first
+    expect = kzg.add(want[0], kzg.multiply(kzg.add(lists[2][5], kzg.neg(ck0[5])), poly[5]))
+    assert got[0] == expect

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile_bench.sh output directory (gpurun_out/prof_<tag>) into
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.csv and profiles/traffic.json.
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.csv, profiles/<tag>_ntt_alone_kernel_stats.csv and
+profiles/counters.json (what bench.py reports as roofline.traffic / roofline.limiter).
 
 HBM bytes follow MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB, collected in
 separate --pmc passes; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane loads, so
-read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B-per-lane stores."""
+read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16-B-per-lane stores.
+SQ_INSTS_VALU counts wave-instructions (one per wave64 instruction issued), summed over the launch."""
 import collections
 import csv
+import glob
 import json
 import os
 import re
@@ -22,49 +25,72 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel)<?", name)
     if "rocprim" in name:
         return "rocprim_scan"
+    m = re.search(r"(\w+_kernel)<?", name)
     return m.group(1) if m else name[:48]
 
 
-rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))))
-with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
-    f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
-    for r in rows:
-        f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
-                f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
-avg_ns = collections.defaultdict(list)
-for r in rows:
-    avg_ns[short(r["Name"])].append((int(r["Calls"]), float(r["AverageNs"])))
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern), recursive=True)
+    return f[0] if f else None
 
-pmc = {}
-for ctr, sub, fn in (("FETCH_SIZE", "pmc_fetch", "fetch_counter_collection.csv"),
-                     ("WRITE_SIZE", "pmc_write", "write_counter_collection.csv")):
-    agg = collections.defaultdict(list)
-    for row in csv.DictReader(open(os.path.join(src, sub, fn))):
-        if row["Counter_Name"] == ctr:
-            agg[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
-    pmc[ctr] = {k: sum(v) / len(v) for k, v in agg.items()}
+
+def stats(path, out_name):
+    rows = list(csv.DictReader(open(path)))
+    with open(os.path.join(dst, out_name), "w") as f:
+        f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+        for r in rows:
+            f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
+                    f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+    return {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+
+
+avg_ns = stats(one("trace/**/*kernel_stats.csv"), f"{tag}_kernel_stats.csv")
+ntt_stats = one("ntt_alone/**/*kernel_stats.csv")
+ntt_alone_ns = stats(ntt_stats, f"{tag}_ntt_alone_kernel_stats.csv") if ntt_stats else {}
+
+pmc = collections.defaultdict(dict)          # counter -> kernel -> average per launch
+for sub in ("pmc_fetch", "pmc_write", "pmc_valu", "pmc_mem"):
+    path = one(sub + "/**/*counter_collection.csv")
+    if not path:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(path)):
+        agg[row["Counter_Name"]][short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    for ctr, per_kernel in agg.items():
+        for k, v in per_kernel.items():
+            pmc[ctr][k] = sum(v) / len(v)
+counters = sorted(pmc)
+kernels = sorted({k for c in pmc.values() for k in c})
 with open(os.path.join(dst, f"{tag}_pmc.csv"), "w") as f:
-    f.write("kernel,FETCH_SIZE_KiB_avg,WRITE_SIZE_KiB_avg,hbm_read_bytes(2x FETCH),hbm_write_bytes,hbm_bytes_per_launch\n")
-    for k in sorted(set(pmc["FETCH_SIZE"]) | set(pmc["WRITE_SIZE"])):
-        fk, wk = pmc["FETCH_SIZE"].get(k, 0.0), pmc["WRITE_SIZE"].get(k, 0.0)
-        f.write(f"{k},{fk:.1f},{wk:.1f},{2 * fk * 1024:.0f},{wk * 1024:.0f},{(2 * fk + wk) * 1024:.0f}\n")
+    f.write("kernel," + ",".join(f"{c}_avg_per_launch" for c in counters) + ",hbm_read_bytes(2x FETCH KiB),hbm_write_bytes,hbm_bytes_per_launch\n")
+    for k in kernels:
+        fk, wk = pmc.get("FETCH_SIZE", {}).get(k, 0.0), pmc.get("WRITE_SIZE", {}).get(k, 0.0)
+        f.write(k + "," + ",".join(f"{pmc[c].get(k, 0.0):.6g}" for c in counters)
+                + f",{2 * fk * 1024:.0f},{wk * 1024:.0f},{(2 * fk + wk) * 1024:.0f}\n")
 
 
 def traffic(k):
-    return (2 * pmc["FETCH_SIZE"].get(k, 0.0) + pmc["WRITE_SIZE"].get(k, 0.0)) * 1024
+    return (2 * pmc.get("FETCH_SIZE", {}).get(k, 0.0) + pmc.get("WRITE_SIZE", {}).get(k, 0.0)) * 1024
+
+
+def valu(k):
+    return pmc.get("SQ_INSTS_VALU", {}).get(k)
 
 
 out = {
-    "source": f"profiles/{tag}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; "
-              "read bytes = 2 x FETCH_SIZE KiB x 1024 per MI355X_MICROARCH.md, gfx950 correction)",
-    "msm_accumulate_kernel": traffic("msm_accumulate_kernel"),
-    "ntt_pass_kernel_per_launch": traffic("ntt_pass_kernel"),
-    "ntt_batch_per_launch": batch,
-    "ntt_pass_kernel_per_transform": 2 * traffic("ntt_pass_kernel") / batch,
+    "source": f"profiles/{tag}_pmc.csv (rocprofv3 --kernel-trace --pmc, one counter group per run: FETCH_SIZE | WRITE_SIZE | "
+              "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES; read bytes = 2 x FETCH_SIZE KiB x 1024, the gfx950 correction of "
+              "MI355X_MICROARCH.md; bench.py --mode batch --steps 3)",
+    "msm_accumulate_kernel": {"hbm_bytes": traffic("msm_accumulate_kernel"),
+                              "valu_wave_instructions": valu("msm_accumulate_kernel"),
+                              "avg_ns_pipelined_under_profiler": avg_ns.get("msm_accumulate_kernel")},
+    "ntt_pass_kernel_per_transform": {"hbm_bytes": 2 * traffic("ntt_pass_kernel") / batch,
+                                      "valu_wave_instructions": (2 * valu("ntt_pass_kernel") / batch) if valu("ntt_pass_kernel") else None,
+                                      "ntt_batch_per_launch": batch,
+                                      "avg_ns_per_launch_alone_under_profiler": ntt_alone_ns.get("ntt_pass_kernel")},
 }
-json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, "counters.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "trace_bench.log"), os.path.join(dst, f"{tag}_bench_under_rocprof.log"))
 print(json.dumps(out, indent=1))

@@ -241,3 +241,64 @@ def test_distributed_ntt_rehearsal_on_one_gpu(native, curve, log_n, world):
             want = kzg._g1.normalize(kzg.multiply(kzg.G1, p_tau))
             got_pt = kzg._g1.normalize(acc)
             assert (int(got_pt[0]), int(got_pt[1])) == (int(want[0]), int(want[1])), "commit of the transposed shards"
+
+
+def test_full_size_2_24_properties(native):
+    """The transform size of BASELINE config 4 (degree 2^24, 512 MiB per vector), device resident:
+    (a) round trip, (b) DFT rows X[k] = sum_j x_j w^(jk) = x(w^k) for scattered k, evaluated by the
+    device's Horner primitive (kzg_fr_poly_eval, itself checked against Python ints in
+    test_vec_gpu.py), (c) linearity with the device's linear-combination primitive."""
+    import torch
+    cv = O.BLS12_381
+    r = cv.r
+    log_n = 24
+    n = 1 << log_n
+    w = cv.root_of_unity(n)
+    ww = native.int_to_words(w)
+    ctx = native.get_context("bls12_381")
+    ctx.bind_torch_stream()
+    g = torch.Generator(device="cuda:0").manual_seed(24)
+    x = torch.randint(0, 1 << 62, (n, 4), generator=g, dtype=torch.int64, device="cuda:0")
+    x[:, 3] >>= 3
+    X = x.clone()
+    ctx.ntt_device(X.data_ptr(), log_n, ww, False, 1)
+    ctx.synchronize()
+    Xh = {k: native.limbs_to_ints(X[k:k + 1].cpu().numpy().view(np.uint64))[0]
+          for k in (0, 1, 2, 4095, 4096, 4097, n // 2, n - 1, 12345678)}
+    for k, got in Xh.items():
+        assert got == ctx.poly_eval(n, x.data_ptr(), pow(w, k, r)), k
+    back = X.clone()
+    ctx.ntt_device(back.data_ptr(), log_n, ww, True, 1)
+    ctx.synchronize()
+    assert torch.equal(back, x)
+    y = torch.randint(0, 1 << 62, (n, 4), generator=g, dtype=torch.int64, device="cuda:0")
+    y[:, 3] >>= 3
+    z = torch.empty_like(x)
+    ctx.vec_lincomb(n, [x.data_ptr(), y.data_ptr()], [n, n], [1, 3], z.data_ptr())       # x + 3y
+    Y = y.clone()
+    ctx.ntt_device(Y.data_ptr(), log_n, ww, False, 1)
+    ctx.ntt_device(z.data_ptr(), log_n, ww, False, 1)
+    want = torch.empty_like(x)
+    ctx.vec_lincomb(n, [X.data_ptr(), Y.data_ptr()], [n, n], [1, 3], want.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(z, want)
+
+
+@pytest.mark.parametrize("curve,n", [("bls12_381", (1 << 16) + 1), ("bn254", 3 * (1 << 14)), ("bls12_381", (1 << 20) - 1)])
+def test_ragged_lengths_at_size(native, curve, n):
+    """fft_ff / ifft_ff on large lengths that are not powers of two (the reference recursion's
+    result, fft_ff.py:15-37) against the C restatement of that recursion (oracle/kzg_oracle.c);
+    the small cases are frozen in tests/golden/ragged_fft_vectors.json."""
+    from oracle import c_oracle as CO
+    cv = O.curve(curve)
+    rs = np.random.RandomState(n % 1000)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(3)
+    w = 0x123456789abcdef % cv.r
+    ctx = native.get_context(curve)
+    for inverse in (False, True):
+        got = raw.copy()
+        ctx.fft_ff_any(got, native.int_to_words(w), inverse)
+        want = raw.copy()
+        CO.fft(curve, want, w, inverse=inverse)
+        assert np.array_equal(got, want), (n, inverse)

@@ -434,20 +434,22 @@ def test_bind_torch_stream_orders_the_default_stream(native):
     by an engine call must see the copied data, and the commit path must accept that stream."""
     import torch
     ctx = native.Context("bls12_381")
-    bound = ctx.bind_torch_stream()
-    assert bound.cuda_stream == torch.cuda.default_stream().cuda_stream
-    n = 1 << 21
-    base = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device="cuda:0")
-    base[:, 3] >>= 3
-    torch.cuda.synchronize()
-    for it in range(8):
-        sl = base[it:it + 2 * n:2].contiguous()              # strided copy on the default stream
-        got = ctx.poly_eval(n, sl.data_ptr(), 12345)          # read at once by the engine
+    default = torch.cuda.default_stream()
+    assert default.cuda_stream == 0
+    with torch.cuda.stream(default):             # other tests may have left another stream current
+        assert ctx.bind_torch_stream().cuda_stream == 0
+        n = 1 << 21
+        base = torch.randint(0, 1 << 62, (2 * n, 4), dtype=torch.int64, device="cuda:0")
+        base[:, 3] >>= 3
         torch.cuda.synchronize()
-        assert got == ctx.poly_eval(n, sl.data_ptr(), 12345)
-    srs = ctx.srs_generate(native.int_to_words(7), 1 << 10)
-    xy, inf = ctx.commit_device(srs, base.data_ptr(), [1 << 10], 1 << 10)     # events / waits on the null stream
-    assert inf[0] == 0
+        for it in range(8):
+            sl = base[it:it + 2 * n:2].contiguous()              # strided copy on the default stream
+            got = ctx.poly_eval(n, sl.data_ptr(), 12345)          # read at once by the engine
+            torch.cuda.synchronize()
+            assert got == ctx.poly_eval(n, sl.data_ptr(), 12345)
+        srs = ctx.srs_generate(native.int_to_words(7), 1 << 10)
+        xy, inf = ctx.commit_device(srs, base.data_ptr(), [1 << 10], 1 << 10)     # events / waits on the null stream
+        assert inf[0] == 0
     ctx.close()
 
 

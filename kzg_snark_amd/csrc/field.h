@@ -38,8 +38,18 @@
 
 namespace kzg {
 
-// c + a*b: one v_mad_u64_u32
-static KZG_HD uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+// c + a*b: one v_mad_u64_u32.  On the device every partial sum is also shown to an EMPTY asm statement as an input:
+// LLVM's Reassociate pass only rewrites chains whose interior sums have a single use, so the column stays ONE
+// multiply-add chain seeded with the carry instead of a chain from zero joined to the carry by a v_lshl_add_u64
+// (one instruction per column).  Nothing is emitted for the statement and, unlike an asm DEFINITION, an asm use
+// draws no hazard nops.
+static KZG_HD uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t c) {
+  const uint64_t r = c + (uint64_t)a * b;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_NO_CHAIN_PIN)
+  asm volatile("" ::"v"(r));
+#endif
+  return r;
+}
 
 template <class F>
 struct Fe {
@@ -55,6 +65,10 @@ struct Field {
   // products of two normalised limbs that fit one 64-bit column (with room for carries)
   static constexpr int CAP = (2 * L >= 64) ? 0 : (int)((1ull << (64 - 2 * L)) - 1);
   static_assert(CAP >= 15, "limb width too large for 64-bit columns");
+  // Exact capacity of a product-scanning column: FIT = 2^(64-2L) products of two limbs <= 2^L - 1 plus the carry of
+  // the previous column still fit 64 bits:  FIT (2^L - 1)^2 + 2^(64-L) = 2^64 - FIT 2^(L+1) + FIT + 2^(64-L) < 2^64
+  // because FIT 2^(L+1) = 2^(65-L) > 2^(64-L) + FIT.  (L = 30: 16 products; L = 29: 64.)
+  static constexpr int FIT = CAP + 1;
   using E = Fe<F>;
 
   // carry-normalise a window of 64-bit columns in place (value unchanged)
@@ -136,8 +150,8 @@ struct Field {
   // added last -- one v_lshl_add_u64 per column remains; forcing a single chain with inline-asm
   // multiply-adds was worth another 0.4 % and was not kept)
   //
-  // Column capacity: products of two L-bit limbs are < 2^(2L); a 64-bit column holds CAP of them
-  // next to the carry.  Columns with more products (L = 30, N = 13: the 11 middle ones) are split:
+  // Column capacity: products of two L-bit limbs are < 2^(2L); a 64-bit column holds FIT of them
+  // next to the carry.  Columns with more products (L = 30, N = 13: the 9 middle ones) are split:
   // the partial sum is cut into its low L bits (which stay in the chain) and its upper part (added
   // to the outgoing carry).  `UA` = how many units one a*b product may take (operands with limbs
   // up to 2^(L+1) from add_lazy count 2 or 4).
@@ -151,7 +165,7 @@ struct Field {
       const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
       const int nab = hi - lo + 1;                       // a*b products of this column
       const int nmp = k < N ? k + 1 : nab;               // m*p products (incl. m_k p_0 in the low half)
-      const bool split = nab * UNITS_AB + nmp > CAP - 1;
+      const bool split = nab * UNITS_AB + nmp > FIT;
       uint64_t upper = 0;
 #pragma unroll
       for (int i = lo; i <= hi; ++i) acc = mad_wide(a.l[i], b.l[k - i], acc);
@@ -183,7 +197,7 @@ struct Field {
       const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
       const int nab = hi - lo + 1;                       // units: a doubled product counts twice
       const int nmp = k < N ? k + 1 : nab;
-      const bool split = nab + nmp > CAP - 1;
+      const bool split = nab + nmp > FIT;
       uint64_t upper = 0;
 #pragma unroll
       for (int i = lo; i <= hi; ++i) {
@@ -220,8 +234,8 @@ struct Field {
       const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
       const int nab = hi - lo + 1;
       const int nmp = k < N ? k + 1 : nab;
-      const bool split1 = 2 * nab > CAP - 1;             // between a*b and c*d
-      const bool split2 = (split1 ? nab : 2 * nab) + nmp > CAP - 1;   // before m*p
+      const bool split1 = 2 * nab > FIT;                 // between a*b and c*d
+      const bool split2 = (split1 ? nab : 2 * nab) + nmp > FIT;       // before m*p
       uint64_t upper = 0;
 #pragma unroll
       for (int i = lo; i <= hi; ++i) acc = mad_wide(a.l[i], b.l[k - i], acc);

@@ -393,6 +393,9 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
 // The reduce-stage kernels run beside the persistent accumulate kernel, which holds 2 waves x 168
 // VGPRs of every SIMD: 176 VGPRs are left of the 512, i.e. the 168 of a 3-waves-per-SIMD budget.
 #define KZG_SIDE_VGPRS __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef KZG_REDUCE_PRIO
+#define KZG_REDUCE_PRIO 3
+#endif
 
 // Skewed scalars (many equal or small coefficients) put thousands of slices into a few buckets.
 // Buckets come in length order, so those are the first ranks: the first HEAVY_RANKS ranks whose
@@ -403,7 +406,7 @@ constexpr uint32_t HEAVY_NS = 64;
 template <class C, int WB>
 __global__ __launch_bounds__(256) KZG_SIDE_VGPRS void msm_finalize_heavy_kernel(const uint32_t* partials, const uint32_t* order,
                                                                  const uint32_t* slice_off, uint32_t* buckets) {
-  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
+  __builtin_amdgcn_s_setprio(KZG_REDUCE_PRIO);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int N = C::Fp::N;
   __shared__ __attribute__((aligned(16))) uint32_t xch[3 * 4 * N];
   const uint32_t r = blockIdx.x;
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256) KZG_SIDE_VGPRS void msm_finalize_heavy_kernel(
 template <class C, int WB>
 __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_finalize_kernel(const uint32_t* partials, const uint32_t* order,
                                                            const uint32_t* slice_off, uint32_t* buckets) {
-  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
+  __builtin_amdgcn_s_setprio(KZG_REDUCE_PRIO);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr uint32_t FIN = Win<WB>::FIN, NB = Win<WB>::NB;
   static_assert(NB % (64 / FIN) == 0, "a wave covers whole ranks inside the bucket range");
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,7 +462,7 @@ constexpr uint32_t RC_L2 = 16;
 template <class C, int WB>
 __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc1_kernel(const uint32_t* buckets, uint32_t* colpart,
                                                       uint32_t* rowpart) {
-  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
+  __builtin_amdgcn_s_setprio(KZG_REDUCE_PRIO);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO;
   constexpr uint32_t NCHR = (1u << LO) / RC_CH;            // chunks per row (interleaved)
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc1_kernel(const uint3
 template <class C, int WB>
 __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc2_kernel(const uint32_t* colpart, const uint32_t* rowpart,
                                                       uint32_t* colsum, uint32_t* rowsum) {
-  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
+  __builtin_amdgcn_s_setprio(KZG_REDUCE_PRIO);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI;
   constexpr uint32_t NCHC = (1u << HI) / RC_CH, NCHR = (1u << LO) / RC_CH;
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_rc2_kernel(const uint3
 template <class C, int WB>
 __global__ __launch_bounds__(128) KZG_SIDE_VGPRS void msm_planes_kernel(const uint32_t* rowsum, const uint32_t* colsum,
                                                          const uint32_t* buckets, uint32_t* out) {
-  __builtin_amdgcn_s_setprio(3);   // short stage beside the long accumulate kernel: win instruction issue
+  __builtin_amdgcn_s_setprio(KZG_REDUCE_PRIO);   // short stage beside the long accumulate kernel: win instruction issue
   constexpr int LO = Win<WB>::LO, HI = Win<WB>::HI, N = C::Fp::N;
   __shared__ __attribute__((aligned(16))) uint32_t xch[4 * N];
   const uint32_t blk = blockIdx.x, tid = threadIdx.x;

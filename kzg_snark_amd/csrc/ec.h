@@ -115,15 +115,17 @@ struct Ec {
   // base fields (R/p = 168 for BN254, 630 for BLS12-381).  Zero tests go through a product, which
   // is weak-normal: Pp = 0 mod p  <=>  PP = 0 mod p (p prime), likewise R and RR.
   // Consumers of the accumulator (add, dbl, to_affine) use X only as a mul/sqr operand.
-  static KZG_HD P madd_finite(const P& a, const E& x2, const E& y2, bool& finite) {
+  // `neg`: add -(x2, y2) instead.  y2 is the table's canonical coordinate; its sign enters the lazy
+  // difference R = (+-S2) - Y1 (Field::sub_carry_cneg) instead of a carried negation of y2 of its own.
+  static KZG_HD P madd_finite(const P& a, const E& x2, const E& y2, bool neg, bool& finite) {
     const E U2 = Fd::mul(x2, a.zz);
     const E S2 = Fd::mul(y2, a.zzz);
     const E Pp = Fd::template sub_carry<8>(U2, a.x);
-    const E R = Fd::template sub_carry<2>(S2, a.y);
+    const E R = Fd::template sub_carry_cneg<2>(S2, neg, a.y);      // S2 < 2p: 2p - S2 in (0, 2p], R < 4p as before
     const E PP = Fd::sqr(Pp);
     if (Fd::is_zero_weak(PP)) {
       if (Fd::is_zero_weak(Fd::sqr(R))) {
-        const P d = dbl_affine(x2, y2);
+        const P d = dbl_affine(x2, Fd::cneg_canonical(y2, neg));
         finite = !is_inf(d);
         return d;
       }

@@ -370,6 +370,21 @@ struct Field {
     r.l[N - 1] = a.l[N - 1] + (kp[N - 1] - b.l[N - 1]) + c;
     return r;
   }
+  // (neg ? 2p - a : a) - b + K*p for normalised a < 2p and b <= K*p: the conditional negation of a is folded
+  // into the carried difference (2 instructions per limb instead of a carried negation of its own).
+  template <int K>
+  static KZG_HD E sub_carry_cneg(const E& a, bool neg, const E& b) {
+    const uint32_t* kp = pkr<K>();
+    E r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const uint32_t aj = neg ? F::P2R[j] - a.l[j] : a.l[j];
+      const uint32_t t = aj + (kp[j] - b.l[j]) + c;
+      if (j < N - 1) { r.l[j] = t & MASK; c = t >> L; } else { r.l[j] = t; }
+    }
+    return r;
+  }
   // a + b + b for normalised operands: value a + 2b, limbs normalised
   static KZG_HD E add_twice_carry(const E& a, const E& b) {
     E r;

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
     // a bucket that is a single slice (the common case) is final; the others go through finalize.
     // One register carries the destination through the loop: bit 31 = "bucket k", else partial t.
     const uint32_t dst = ns == 1 ? (k | 0x80000000u) : t;
-    XYZZ<C> acc = Ec<C>::infinity();
+    // The accumulator starts as "infinity" (finite == false) with ZZ = ZZZ = 1 already in place: the first
+    // finite entry then only copies its coordinates (the Montgomery one is not re-materialised per iteration).
+    XYZZ<C> acc;
+    acc.x = Fd::zero(); acc.y = Fd::zero(); acc.zz = Fd::one(); acc.zzz = Fd::one();
     bool finite = false;                       // accumulator is the point at infinity
     uint32_t v_cur = 0, v_next = 0;
     uint32_t it = 0;                            // the same for every lane still in the loop
@@ -377,12 +380,12 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
       Fe<F> x, y;
       const uint32_t flag = St::read(cur, lane, x, y);    // table coordinates are canonical
       if (flag & 1u) continue;                            // key point at infinity contributes nothing
-      y = Fd::cneg_canonical(y, v >> 31);
       if (!finite) {
-        acc.x = x; acc.y = y; acc.zz = Fd::one(); acc.zzz = Fd::one();
+        acc.x = x; acc.y = Fd::cneg_canonical(y, v >> 31);
         finite = true;
       } else {
-        acc = Ec<C>::madd_finite(acc, x, y, finite);
+        acc = Ec<C>::madd_finite(acc, x, y, (v >> 31) != 0, finite);
+        if (!finite) { acc.zz = Fd::one(); acc.zzz = Fd::one(); }     // back to "infinity": restore the invariant
       }
     }
     if (!finite) acc = Ec<C>::infinity();

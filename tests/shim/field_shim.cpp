@@ -51,6 +51,8 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
       for (int j = 0; j < F::N; ++j) if (again.l[j] != R.l[j]) R = Fd::zero();
       break;
     }
+    case 18: R = Fd::mul(Fd::template sub_carry_cneg<2>(Fd::mul(A, Fd::one()), true, Fd::mul(B, Fd::one())), Fd::one()); break;    // -a - b
+    case 19: R = Fd::mul(Fd::template sub_carry_cneg<2>(Fd::mul(A, Fd::one()), false, Fd::mul(B, Fd::one())), Fd::one()); break;   //  a - b
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);
@@ -97,11 +99,14 @@ static int ec_op(int which, const uint32_t* p1, int inf1, const uint32_t* p2, in
     case 4: {  // the MSM inner loop form: flag-tracked accumulator, A + B - B + B + A (passes through infinity? no: through A)
       bool fin = true;
       XYZZ<C> t = E::from_affine(A);
-      auto step = [&](const Affine<C>& q, bool negate) {
-        const auto y = Fd::cneg_canonical(Fd::reduce(q.y), negate);
+      auto step = [&](const Affine<C>& q, bool negate) {      // the loop body of msm_accumulate_kernel
+        const auto y = Fd::reduce(q.y);
         const auto x = Fd::reduce(q.x);
-        if (!fin) { t.x = x; t.y = y; t.zz = Fd::one(); t.zzz = Fd::one(); fin = true; }
-        else t = E::madd_finite(t, x, y, fin);
+        if (!fin) { t.x = x; t.y = Fd::cneg_canonical(y, negate); fin = true; }
+        else {
+          t = E::madd_finite(t, x, y, negate, fin);
+          if (!fin) { t.zz = Fd::one(); t.zzz = Fd::one(); }
+        }
       };
       step(B, false); step(B, true); step(A, true);      // A + B - B - A = O
       if (fin) return -2;
@@ -115,10 +120,13 @@ static int ec_op(int which, const uint32_t* p1, int inf1, const uint32_t* p2, in
       for (int i = 0; i < 48; ++i) {
         const Affine<C>& q = (i % 3 == 0) ? A : B;
         const bool negate = (i % 5 == 4);
-        const auto y = Fd::cneg_canonical(Fd::reduce(q.y), negate);
+        const auto y = Fd::reduce(q.y);
         const auto x = Fd::reduce(q.x);
-        if (!fin) { t.x = x; t.y = y; t.zz = Fd::one(); t.zzz = Fd::one(); fin = true; }
-        else t = E::madd_finite(t, x, y, fin);
+        if (!fin) { t.x = x; t.y = Fd::cneg_canonical(y, negate); fin = true; }
+        else {
+          t = E::madd_finite(t, x, y, negate, fin);
+          if (!fin) { t.zz = Fd::one(); t.zzz = Fd::one(); }
+        }
       }
       // the consumers of such an accumulator: a full addition and a doubling
       R = fin ? E::dbl(E::add(t, E::from_affine(B))) : E::infinity();

@@ -41,7 +41,8 @@ def test_field_ops(shim, fid, p, nw):
            (9, lambda a, b: (a - b) * (a - b) % p), (10, lambda a, b: (b - a) % p), (11, lambda a, b: (-a) % p),
            (12, lambda a, b: a % p), (13, lambda a, b: 1 if (a - b) % p == 0 else 0),
            (14, lambda a, b: (a + 2 * b) * (a - b) % p), (15, lambda a, b: (2 * a - b) ** 2 % p),
-           (16, lambda a, b: ((a - b) * (2 * a - b) - a * b) % p), (17, lambda a, b: (16 * a + 15 * b) % p)]
+           (16, lambda a, b: ((a - b) * (2 * a - b) - a * b) % p), (17, lambda a, b: (16 * a + 15 * b) % p),
+           (18, lambda a, b: (-a - b) % p), (19, lambda a, b: (a - b) % p)]
     for _ in range(1500):
         a = rng.choice([0, 1, 2, p - 1, p - 2, rng.randrange(p), rng.randrange(p), 1 << (p.bit_length() - 1)])
         b = rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)])
@@ -98,8 +99,9 @@ def test_ec_ops(shim, cid, cv, nw):
             check(op, inf, inf, inf)
     check(2, a, a, O.double(a, cv))       # dbl
     check(2, inf, inf, inf)
-    # the MSM inner loop (flag-tracked infinity, conditional negation): a + b - b - a = O, then + b + b + a
+    # the MSM inner loop (flag-tracked infinity, sign folded into the lazy difference): a + b - b - a = O, then + b + b + a
     check(4, a, b, O.add(O.double(b, cv), a, cv))
+    check(4, a, O.neg(a, cv), O.add(O.double(O.neg(a, cv), cv), a, cv))     # a - a (O) + a (copy) ... then -a -a + a
     # 48 flag-tracked steps (lazy X range of madd_finite), then a full add and a doubling of the result
     t = a
     for i in range(48):

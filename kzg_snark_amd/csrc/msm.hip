@@ -395,7 +395,10 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
 
 // The reduce-stage kernels run beside the persistent accumulate kernel, which holds 2 waves x 168
 // VGPRs of every SIMD: 176 VGPRs are left of the 512, i.e. the 168 of a 3-waves-per-SIMD budget.
-#define KZG_SIDE_VGPRS __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef KZG_SIDE_WAVES
+#define KZG_SIDE_WAVES 3
+#endif
+#define KZG_SIDE_VGPRS __attribute__((amdgpu_waves_per_eu(KZG_SIDE_WAVES, KZG_SIDE_WAVES)))
 #ifndef KZG_REDUCE_PRIO
 #define KZG_REDUCE_PRIO 3
 #endif

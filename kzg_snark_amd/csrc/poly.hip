@@ -12,6 +12,9 @@
 // are pushed back down, each thread re-walking its chunk from the carry above.
 // Cost: ~2 Montgomery multiplications per coefficient, all data HBM-streamed
 // twice.  The MSM of the quotient (msm.hip) dominates open() by far.
+// These kernels are bound by dependent Horner chains and by memory latency, not by instruction issue: the chain pin of
+// field.h (an asm volatile per multiply-add) would only keep the scheduler from hoisting the next loads.
+#define KZG_NO_CHAIN_PIN 1
 #include "internal.h"
 #include "msm.h"
 #include <algorithm>

@@ -171,6 +171,14 @@ int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const
                     size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
                     uint64_t* eval_out);
 
+/* Pipelined form of kzg_open_device: the combine / evaluate / divide kernels and the MSM of the witness are only
+ * enqueued (the MSM shares the commit pipeline's slots with kzg_commit_device_async); out_xy, out_inf and eval_out
+ * (required, 4 limbs) are written when kzg_commit_flush() returns or a later call recycles the slot.  The input
+ * polynomials may be overwritten by later work on the context's stream as soon as the call has returned. */
+int kzg_open_device_async(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const size_t* lens, size_t k,
+                          size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
+                          uint64_t* eval_out);
+
 /* ---- KZG.open on ONE polynomial set partitioned by coefficient range across GPUs ----------------
  * Rank g holds coefficients [lo_g, hi_g) of every polynomial (the same ranges for all) and a key
  * shard.  kzg_open_shard_begin combines the slices (sum xi^(i+1) p_i) and returns the slice

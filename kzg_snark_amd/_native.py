@@ -71,6 +71,7 @@ SIGNATURES = {
     "kzg_prof_reset": (ctypes.c_int, [_vp]),
     "kzg_prof_read": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]),
+    "kzg_open_device_async": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
     "kzg_open_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -302,6 +303,14 @@ class Context:
                        _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf), _as_vp(ev)))
         return out_xy, out_inf, ev
 
+
+    def open_device_async(self, srs, d_polys, lens, stride, z_words, xi_words, out_xy, out_inf, eval_out):
+        """Pipelined open: out_xy (uint64[2*fp_limbs]), out_inf (uint8[1]) and eval_out (uint64[4]) -- numpy arrays
+        the caller keeps alive -- are filled by the time commit_flush() returns."""
+        lens_a = np.asarray(lens, dtype=np.uint64)
+        self._check(lib().kzg_open_device_async(self._h, srs._h, _as_vp(d_polys), _as_vp(lens_a), len(lens), stride,
+                                                _as_vp(z_words), _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf),
+                                                _as_vp(eval_out)))
 
     # ---- device vector / polynomial primitives (device pointers, canonical elements)
     def vec_op(self, op, n, d_a, d_b, d_out):

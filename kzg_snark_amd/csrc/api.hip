@@ -347,6 +347,37 @@ int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const
   return commit_device(c, srs->s, d_quot, &qlen, 1, qlen ? qlen : 1, out_xy, out_inf);
 }
 
+int kzg_open_device_async(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const size_t* lens, size_t k,
+                          size_t stride, const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf,
+                          uint64_t* eval_out) {
+  if (!ctx || !srs || !z || !xi || !out_xy || !out_inf || !eval_out || (k && (!lens || !d_polys))) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  uint32_t* d_quot = nullptr;
+  size_t qlen = 0;
+  int rc = open_quotient_device(c, static_cast<const uint32_t*>(d_polys), lens, k, stride,
+                                reinterpret_cast<const uint32_t*>(z), reinterpret_cast<const uint32_t*>(xi), &d_quot,
+                                &qlen, eval_out, /*sync=*/false);
+  if (rc) return rc;
+  if (!d_quot) {   // every polynomial empty: witness 0, evaluation 0 (already in eval_out)
+    memset(out_xy, 0, (size_t)kzg_fp_limbs(c->curve) * 16);
+    *out_inf = 1;
+    memset(eval_out, 0, 32);
+    return KZG_OK;
+  }
+  const size_t srs_n = srs->s->n;
+  if (qlen > srs_n) {   // rare: the degree check of kzg.py:103 needs the coefficients beyond the key, which synchronises
+    bool nz = false;
+    rc = device_any_nonzero(c, d_quot, srs_n, qlen, &nz);
+    if (rc) return rc;
+    if (nz) return set_err(c, KZG_ERR_DEGREE, "witness polynomial longer than the commitment key");
+    qlen = srs_n;
+  }
+  // S_0 = combined(z) sits right below the quotient in the scan's buffer (poly.hip layout)
+  return commit_device(c, srs->s, d_quot, &qlen, 1, qlen ? qlen : 1, out_xy, out_inf, /*drain=*/false, d_quot - 8,
+                       eval_out);
+}
+
 int kzg_open(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* polys, const size_t* lens, size_t k, size_t stride,
              const uint64_t z[4], const uint64_t xi[4], uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out) {
   if (!ctx || !srs || !z || !xi || !out_xy || !out_inf || (k && (!lens || !polys))) return KZG_ERR_ARG;

@@ -25,8 +25,11 @@ void srs_free(Srs* s);
 // One MSM per polynomial; scalars device-resident, results to host memory (synchronises).
 // drain = false leaves up to four polynomials in flight; their outputs are written when their
 // slot is recycled by a later call or by commit_flush().
+// d_eval / out_eval (pipelined open, n_polys == 1): 32 bytes at d_eval -- written by work already enqueued on the
+// context's stream -- are delivered to out_eval when the polynomial's slot is retired, together with its point.
 int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
-                  size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain = true);
+                  size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain = true,
+                  const uint32_t* d_eval = nullptr, uint64_t* out_eval = nullptr);
 int commit_flush(Ctx* c);
 void msm_free_work(Ctx* c);
 
@@ -34,7 +37,7 @@ void msm_free_work(Ctx* c);
 // d_quot receives max_len-1 coefficients (canonical words); eval_out the value combined(z).
 int open_quotient_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                          const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out,
-                         size_t* quot_len, uint64_t* eval_out);
+                         size_t* quot_len, uint64_t* eval_out, bool sync = true);
 
 int open_shard_begin_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                             const uint32_t* z_words, const uint32_t* xi_words, uint64_t* chunk_eval_out);

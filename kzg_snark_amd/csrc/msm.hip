@@ -707,7 +707,8 @@ constexpr int NSLOT = 4;
 struct MsmSlot {
   DevBuf prep_ws, vals, bstart, order, slice_off, counter, chunk_rank;              // prep
   DevBuf partials, buckets, rowsum, colsum, rowpart, colpart, tb;
-  void* h_tb = nullptr;        // pinned host copy of the partial points
+  void* h_tb = nullptr;        // pinned host copy of the partial points (+ 32 bytes behind them: P(z) of a pipelined open)
+  uint64_t* out_eval = nullptr;   // where that P(z) goes when the slot is retired
   hipEvent_t ev_in = nullptr;  // inputs ready on the context's stream
   hipEvent_t ev_p = nullptr;   // prep done
   hipEvent_t ev_a = nullptr;   // accumulate done
@@ -770,7 +771,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   if ((rc = ensure_buf(c, sl.counter, 256))) return rc;
   const uint32_t nchunk_max = max_slices / 64 + 1;
   if ((rc = ensure_buf(c, sl.chunk_rank, (size_t)nchunk_max * 4))) return rc;
-  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4));
+  if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4 + 32));
   for (hipEvent_t* e : {&sl.ev_in, &sl.ev_p, &sl.ev_a, &sl.ev_b})
     if (!*e) KZG_HIP(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
   if (!w->stream_a) {
@@ -890,6 +891,10 @@ static int msm_retire(Ctx* c, MsmSlot& sl) {
   KZG_HIP(c, hipEventSynchronize(sl.ev_b));
   if (sl.win_bits == 20) msm_finish_host<C, 20>(sl.h_tb, sl.out_xy, sl.out_inf);
   else msm_finish_host<C, 16>(sl.h_tb, sl.out_xy, sl.out_inf);
+  if (sl.out_eval) {      // copied on the context's stream before this slot's prep was allowed to start
+    memcpy(sl.out_eval, static_cast<const char*>(sl.h_tb) + MAX_NPART * 4 * 16 * 4, 32);
+    sl.out_eval = nullptr;
+  }
   sl.pending = false;
   return KZG_OK;
 }
@@ -909,7 +914,8 @@ static int commit_flush_t(Ctx* c) {
 
 template <class C>
 static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
-                    size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain) {
+                    size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain, const uint32_t* d_eval,
+                    uint64_t* out_eval) {
   using F = typename C::Fp;
   MsmWork* w = get_work(c);
   for (size_t p = 0; p < n_polys; ++p) {
@@ -922,12 +928,24 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     if (lens[p] == 0) {   // zero polynomial: Z1 (kzg.py:109)
       memset(o, 0, 2 * F::NW * 4);
       out_inf[p] = 1;
+      if (d_eval && out_eval) {     // nothing to pipeline behind: fetch P(z) now
+        KZG_HIP(c, hipMemcpyAsync(out_eval, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+        KZG_HIP(c, hipStreamSynchronize(c->stream));
+      }
       continue;
     }
     const int si = w->next;
     MsmSlot& sl = w->slot[si];
     w->next = (w->next + 1) % NSLOT;
     if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
+    if (d_eval && out_eval) {
+      // P(z) rides with the slot: the copy is ordered on the context's stream BEFORE ev_in, which every stage of
+      // this polynomial waits for, so it has landed when the slot's last event (ev_b) has
+      if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4 + 32));
+      KZG_HIP(c, hipMemcpyAsync(static_cast<char*>(sl.h_tb) + MAX_NPART * 4 * 16 * 4, d_eval, 32,
+                                hipMemcpyDeviceToHost, c->stream));
+      sl.out_eval = out_eval;
+    }
     const uint32_t* sc = d_scalars + p * stride * 8;
     rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, si)
                            : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, si);
@@ -946,10 +964,13 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
 int commit_flush(Ctx* c) { return c->curve == 0 ? commit_flush_t<Bn254>(c) : commit_flush_t<Bls12_381>(c); }
 
 int commit_device(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_t* lens, size_t n_polys,
-                  size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain) {
+                  size_t stride, uint64_t* out_xy, uint8_t* out_inf, bool drain, const uint32_t* d_eval,
+                  uint64_t* out_eval) {
   if (s->curve != c->curve) return set_err(c, KZG_ERR_ARG, "SRS belongs to another curve");
-  return c->curve == 0 ? commit_t<Bn254>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain)
-                       : commit_t<Bls12_381>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain);
+  if (d_eval && n_polys != 1) return set_err(c, KZG_ERR_ARG, "an evaluation rides with exactly one polynomial");
+  return c->curve == 0
+             ? commit_t<Bn254>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain, d_eval, out_eval)
+             : commit_t<Bls12_381>(c, s, d_scalars, lens, n_polys, stride, out_xy, out_inf, drain, d_eval, out_eval);
 }
 
 }  // namespace kzg

@@ -28,11 +28,16 @@ namespace {
 constexpr uint32_t LC = 32;       // coefficients per chunk
 constexpr uint32_t MAXK = 64;     // polynomials per open()
 
-struct LincombArgs {
+constexpr int FRN = 9;            // both scalar fields: 9 x 29-bit limbs
+struct LincombArgs {              // travels in the kernel arguments (2.6 KB): no staging copy, no host synchronisation
   const uint32_t* polys;     // k polynomials, `stride` elements apart, canonical words
   uint64_t stride;
   uint32_t k;
   uint32_t lens[MAXK];
+  uint32_t xipow[MAXK * FRN];   // xi^(i+1), Montgomery form
+};
+struct FrArg {                    // one field element (Montgomery limbs) as a kernel argument
+  uint32_t l[FRN];
 };
 
 template <class F>
@@ -65,15 +70,16 @@ __device__ __forceinline__ void store_limbs(uint32_t* p, const Fe<F>& v) {
 
 // out[t] = sum_i xipow[i] * p_i[t]   (xipow in Montgomery form => result in standard form)
 template <class F>
-__global__ void lincomb_kernel(LincombArgs a, const uint32_t* xipow, uint32_t* out, uint32_t n) {
+__global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
   using Fd = Field<F>;
+  static_assert(F::N == FRN, "scalar fields have 9 limbs");
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   Fe<F> acc = Fd::zero();
   for (uint32_t i = 0; i < a.k; ++i) {
     if (t < a.lens[i]) {
       const Fe<F> c = load_words<F>(a.polys + (a.stride * i + t) * 8);
-      acc = Fd::add(acc, Fd::mul(c, load_limbs<F>(xipow + i * F::N)));
+      acc = Fd::add(acc, Fd::mul(c, load_limbs<F>(a.xipow + i * F::N)));
     }
   }
   store_words<F>(out + (size_t)t * 8, acc);
@@ -81,13 +87,13 @@ __global__ void lincomb_kernel(LincombArgs a, const uint32_t* xipow, uint32_t* o
 
 // bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*LC)
 template <class F, bool WORDS_IN>
-__global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, const uint32_t* zpow, uint32_t* h) {
+__global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* h) {
   using Fd = Field<F>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t j0 = t * LC;
   if (j0 >= m) return;
   const uint32_t j1 = min(j0 + LC, m);
-  const Fe<F> z = load_limbs<F>(zpow);
+  const Fe<F> z = load_limbs<F>(zpow.l);
   Fe<F> acc = Fd::zero();
   for (uint32_t j = j1; j-- > j0;) {
     const Fe<F> c = WORDS_IN ? load_words<F>(in + (size_t)j * 8) : load_limbs<F>(in + (size_t)j * F::N);
@@ -98,10 +104,10 @@ __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, const uint32_t
 
 // top level (m <= LC): S[j] = c_j + z*S[j+1], S[m] = 0; one thread
 template <class F>
-__global__ void top_suffix_kernel(const uint32_t* in, uint32_t m, const uint32_t* zpow, uint32_t* S) {
+__global__ void top_suffix_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* S) {
   using Fd = Field<F>;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const Fe<F> z = load_limbs<F>(zpow);
+  const Fe<F> z = load_limbs<F>(zpow.l);
   Fe<F> acc = Fd::zero();
   store_limbs<F>(S + (size_t)m * F::N, acc);
   for (uint32_t j = m; j-- > 0;) {
@@ -113,14 +119,14 @@ __global__ void top_suffix_kernel(const uint32_t* in, uint32_t m, const uint32_t
 // top-down: S[j] for j in chunk t, starting from the carry S_up[t+1].
 // FINAL: input is the coefficient array (words); writes quotient q[j-1] = S_j and eval = S_0.
 template <class F, bool FINAL>
-__global__ void chunk_fill_kernel(const uint32_t* in, uint32_t m, const uint32_t* zpow, const uint32_t* S_up,
+__global__ void chunk_fill_kernel(const uint32_t* in, uint32_t m, FrArg zpow, const uint32_t* S_up,
                                   uint32_t* S_out, uint32_t* quot, uint32_t* eval_out) {
   using Fd = Field<F>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t j0 = t * LC;
   if (j0 >= m) return;
   const uint32_t j1 = min(j0 + LC, m);
-  const Fe<F> z = load_limbs<F>(zpow);
+  const Fe<F> z = load_limbs<F>(zpow.l);
   Fe<F> acc = load_limbs<F>(S_up + (size_t)(t + 1) * F::N);
   if (!FINAL && t == 0 && j1 == m) { /* single chunk: nothing above */ }
   for (uint32_t j = j1; j-- > j0;) {
@@ -161,63 +167,56 @@ int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k
   *n_out = n;
   if (n == 0) return KZG_OK;
   if (n >= (1ull << 31) - 1) return set_err(c, KZG_ERR_ARG, "kzg_open: polynomial too long");
-  const Fe<F> xi = Fd::to_mont(Fd::from_words(xi_words));
-  std::vector<uint32_t> hs(k * F::N);
-  Fe<F> xp = Fd::one();
-  for (size_t i = 0; i < k; ++i) {
-    xp = Fd::mul(xp, xi);
-    memcpy(&hs[i * F::N], xp.l, F::N * 4);
-  }
   int rc;
   if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * (n + 1) + 1) * 32))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[1], (k + 16) * F::N * 4))) return rc;
   uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
-  uint32_t* d_sc = static_cast<uint32_t*>(c->poly_tmp[1].p);
-  if (k) {
-    KZG_HIP(c, hipMemcpyAsync(d_sc, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
-    KZG_HIP(c, hipStreamSynchronize(c->stream));     // hs is a local vector
-  }
   ProfScope ps(c, "open_poly");
   LincombArgs la{};
   la.polys = d_polys; la.stride = stride; la.k = (uint32_t)k;
-  for (size_t i = 0; i < k; ++i) la.lens[i] = (uint32_t)lens[i];
-  hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_sc, d_comb,
+  const Fe<F> xi = Fd::to_mont(Fd::from_words(xi_words));
+  Fe<F> xp = Fd::one();
+  for (size_t i = 0; i < k; ++i) {
+    xp = Fd::mul(xp, xi);                                   // xi^(i+1): kzg.py:148-150
+    memcpy(&la.xipow[i * F::N], xp.l, F::N * 4);
+    la.lens[i] = (uint32_t)lens[i];
+  }
+  hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_comb,
                      (uint32_t)n);
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
 }
 
 // Suffix-Horner scan of comb[0 .. n) (n >= 1) at z: eval <- S_0, quot[j-1] <- S_j.  `cap` fixes the layout.
+// eval_out: host memory that receives S_0 (the call then synchronises the stream), or nullptr: nothing is copied and
+// nothing waits -- the pipelined open fetches the 32 bytes at comb + cap*8 itself (msm.hip, commit_device).
 template <class F>
-int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out) {
+int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out, bool sync = true) {
   using Fd = Field<F>;
   std::vector<uint32_t> m{(uint32_t)n};
   while (m.back() > LC) m.push_back((m.back() + LC - 1) / LC);
   const size_t nl = m.size();
-  const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
-  std::vector<uint32_t> hs(nl * F::N);
-  Fe<F> zp = z;
-  for (size_t l = 0; l < nl; ++l) {
-    memcpy(&hs[l * F::N], zp.l, F::N * 4);
-    for (int q = 0; q < 5; ++q) zp = Fd::mul(zp, zp);     // ^32 = ^LC
+  std::vector<FrArg> zp(nl);                              // z^(LC^l), Montgomery form, passed by value
+  {
+    Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
+    for (size_t l = 0; l < nl; ++l) {
+      memcpy(zp[l].l, t.l, F::N * 4);
+      for (int q = 0; q < 5; ++q) t = Fd::mul(t, t);        // ^32 = ^LC
+    }
   }
-  static_assert(LC == 32, "zp update assumes LC = 2^5");
+  static_assert(LC == 32, "the power update assumes LC = 2^5");
   size_t hl_total = 0, sl_total = 0;
   for (size_t l = 1; l < nl; ++l) { hl_total += m[l]; sl_total += m[l] + 1; }
   int rc;
   if ((rc = ensure_buf(c, c->poly_tmp[2], (hl_total + 1) * F::N * 4))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[3], (sl_total + 2 + nl) * F::N * 4))) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[3], (sl_total + 2) * F::N * 4))) return rc;
   uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
   uint32_t* d_eval = d_comb + cap * 8;
   uint32_t* d_quot = d_eval + 8;
   uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
   uint32_t* d_S = static_cast<uint32_t*>(c->poly_tmp[3].p);
-  uint32_t* d_zp = d_S + (sl_total + 2) * F::N;           // z^(LC^l) limbs behind the suffix arrays
-  KZG_HIP(c, hipMemcpyAsync(d_zp, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
-  KZG_HIP(c, hipStreamSynchronize(c->stream));
 
   ProfScope ps(c, "open_poly");
-  auto zpow = [&](size_t l) { return d_zp + l * F::N; };
+  auto zpow = [&](size_t l) { return zp[l]; };
   std::vector<uint32_t*> hptr(nl, nullptr), sptr(nl, nullptr);
   {
     uint32_t* hp = d_h; uint32_t* sp = d_S;
@@ -243,23 +242,26 @@ int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t*
                        zpow(0), sptr[1], (uint32_t*)nullptr, d_quot, d_eval);
   }
   KZG_HIP(c, hipGetLastError());
-  KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
-  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  if (eval_out) {
+    KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  (void)sync;
   return KZG_OK;
 }
 
 template <class F>
 int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                     const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out, size_t* quot_len,
-                    uint64_t* eval_out) {
-  memset(eval_out, 0, 32);
+                    uint64_t* eval_out, bool sync) {
+  if (eval_out) memset(eval_out, 0, 32);
   *quot_len = 0;
   *d_quot_out = nullptr;
   size_t n = 0;
   int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n);
   if (rc) return rc;
   if (n == 0) return KZG_OK;     // all polynomials zero: witness 0, evaluation 0
-  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, eval_out))) return rc;
+  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, sync ? eval_out : nullptr, sync))) return rc;
   *d_quot_out = static_cast<uint32_t*>(c->poly_tmp[0].p) + (n + 1) * 8 + 8;
   *quot_len = n - 1;
   return KZG_OK;
@@ -308,10 +310,11 @@ int open_shard_finish_t(Ctx* c, const uint32_t* z_words, const uint32_t* carry_w
 
 int open_quotient_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                          const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out, size_t* quot_len,
-                         uint64_t* eval_out) {
-  return c->curve == 0
-             ? open_quotient_t<BnFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len, eval_out)
-             : open_quotient_t<BlsFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len, eval_out);
+                         uint64_t* eval_out, bool sync) {
+  return c->curve == 0 ? open_quotient_t<BnFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len,
+                                               eval_out, sync)
+                       : open_quotient_t<BlsFr>(c, d_polys, lens, k, stride, z_words, xi_words, d_quot_out, quot_len,
+                                                eval_out, sync);
 }
 
 int open_shard_begin_device(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
@@ -608,23 +611,19 @@ int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, ui
   std::vector<uint32_t> m{(uint32_t)n};
   while (m.back() > 1) m.push_back((m.back() + LC - 1) / LC);
   const size_t nl = m.size();
-  std::vector<uint32_t> hs(nl * F::N);
-  Fe<F> zp = Fd::to_mont(Fd::from_words(z_words));
-  for (size_t l = 0; l < nl; ++l) {
-    memcpy(&hs[l * F::N], zp.l, F::N * 4);
-    for (int q = 0; q < 5; ++q) zp = Fd::mul(zp, zp);
+  std::vector<FrArg> zp(nl);                              // z^(LC^l), passed to the kernels by value
+  {
+    Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
+    for (size_t l = 0; l < nl; ++l) {
+      memcpy(zp[l].l, t.l, F::N * 4);
+      for (int q = 0; q < 5; ++q) t = Fd::mul(t, t);
+    }
   }
   size_t total = 0;
   for (size_t l = 1; l < nl; ++l) total += m[l];
   int rc;
   if ((rc = ensure_buf(c, c->poly_tmp[2], (total + 1) * F::N * 4))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[3], (nl + 2) * F::N * 4 + 64))) return rc;
   uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
-  uint32_t* d_zp = static_cast<uint32_t*>(c->poly_tmp[3].p);
-  uint32_t* d_out = d_zp + (nl + 1) * F::N;
-  d_out += (8 - ((uintptr_t)d_out / 4) % 8) % 8;      // 32-byte alignment for the uint4 store
-  KZG_HIP(c, hipMemcpyAsync(d_zp, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, c->stream));
-  KZG_HIP(c, hipStreamSynchronize(c->stream));
   if (nl == 1) {     // n == 1: the value is the coefficient itself
     KZG_HIP(c, hipMemcpyAsync(out, a, 32, hipMemcpyDeviceToHost, c->stream));
     KZG_HIP(c, hipStreamSynchronize(c->stream));
@@ -633,10 +632,10 @@ int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, ui
   std::vector<uint32_t*> hp(nl, nullptr);
   { uint32_t* x = d_h; for (size_t l = 1; l < nl; ++l) { hp[l] = x; x += (size_t)m[l] * F::N; } }
   hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, a, m[0],
-                     d_zp, hp[1]);
+                     zp[0], hp[1]);
   for (size_t l = 1; l + 1 < nl; ++l)
     hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hp[l],
-                       m[l], d_zp + l * F::N, hp[l + 1]);
+                       m[l], zp[l], hp[l + 1]);
   KZG_HIP(c, hipGetLastError());
   // the top level holds one weak-normal value (standard form): canonicalise on the host
   uint32_t top[F::N];
@@ -645,7 +644,6 @@ int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, ui
   Fe<F> v;
   memcpy(v.l, top, F::N * 4);
   Fd::to_words(Fd::reduce(v), reinterpret_cast<uint32_t*>(out));
-  (void)d_out;
   return KZG_OK;
 }
 

@@ -472,3 +472,49 @@ def test_list_form_key_cache_is_bounded_and_notices_edits(kzgs):
     assert got != want and kzg._loaded[id(lists[2])][0] is not first
     expect = kzg.add(want[0], kzg.multiply(kzg.add(lists[2][5], kzg.neg(ck0[5])), poly[5]))
     assert got[0] == expect
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_pipelined_open_matches_the_synchronous_one(native, curve):
+    """kzg_open_device_async: more openings than pipeline slots, interleaved with pipelined commits, the SAME device
+    buffer refilled between calls; every proof point and P(z) must equal what kzg_open_device returns for the same
+    inputs (which the other tests pin to the oracle and the trapdoor), incl. a constant and an all-zero batch."""
+    import torch
+    cv = O.curve(curve)
+    ctx = native.Context(curve)
+    stream = torch.cuda.Stream(device="cuda:0")
+    ctx.bind_torch_stream(stream)
+    L = ctx.fp_limbs
+    n = (1 << 16) + 5
+    tau = 0x7777777777 % cv.r
+    srs = ctx.srs_generate(native.int_to_words(tau), n)
+    rng = random.Random(99)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    cases = [([n, n - 1, 777], False), ([n], False), ([1, 1], False), ([0, 0], True), ([n - 7, n], False),
+             ([n, n, n, n, n, n], False), ([5], False)]
+    jobs = []
+    with torch.cuda.stream(stream):
+        buf = torch.zeros((6, n, 4), dtype=torch.int64, device="cuda:0")
+        for lens, _ in cases:
+            k = len(lens)
+            fresh = torch.randint(0, 1 << 62, (6, n, 4), generator=g, dtype=torch.int64, device="cuda:0")
+            fresh[..., 3] >>= 3
+            z, xi = rng.randrange(cv.r), rng.randrange(cv.r)
+            zw, xw = native.int_to_words(z), native.int_to_words(xi)
+            want = ctx.open(srs, fresh.data_ptr(), lens, n, zw, xw, device=True)       # synchronous reference
+            buf.copy_(fresh)                                                             # overwrite the shared buffer
+            out = (np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros(4, dtype=np.uint64))
+            ctx.open_device_async(srs, buf.data_ptr(), lens[:k], n, zw, xw, *out)
+            cxy, cinf = np.zeros((1, 2 * L), dtype=np.uint64), np.zeros(1, dtype=np.uint8)
+            ctx.commit_device_async(srs, buf.data_ptr(), [lens[0]], n, cxy, cinf)      # shares the slots
+            cwant = ctx.poly_eval(lens[0], fresh.data_ptr(), tau) if lens[0] else None
+            jobs.append((want, out, (cxy, cinf, cwant)))
+        ctx.commit_flush()
+    G1 = O.from_affine(cv.g1)
+    for (wxy, winf, wev), (xy, inf, ev), (cxy, cinf, cwant) in jobs:
+        assert inf[0] == winf[0] and np.array_equal(xy, wxy) and np.array_equal(ev, wev)
+        if cwant is None:
+            assert cinf[0] == 1
+        else:
+            assert tuple(native.limbs_to_ints(cxy[0].reshape(2, L))) == O.normalize(O.multiply(G1, cwant, cv), cv)
+    ctx.close()

@@ -291,11 +291,17 @@ class DeviceProver:
         stride = n + 6
         pack = torch.stack([alg.padded(p, stride) for p in polys]).contiguous()
         zw_ = _native.int_to_words
-        xy, inf, _ = alg.ctx.open(ck.srs, pack.data_ptr(), [p.shape[0] for p in polys], stride, zw_(zeta), zw_(v), device=True)
-        W_z = kzg._points(xy, inf)[0]
+        # the two openings (plonk/prover.py:184-185) are independent: both go through the pipelined entry point
+        # and their witness MSMs overlap; results arrive at the flush
+        L = alg.ctx.fp_limbs
+        o1 = (np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros(4, dtype=np.uint64))
+        o2 = (np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros(4, dtype=np.uint64))
+        alg.ctx.open_device_async(ck.srs, pack.data_ptr(), [p.shape[0] for p in polys], stride, zw_(zeta), zw_(v), *o1)
         zpack = alg.padded(z_c, stride)
-        xy, inf, _ = alg.ctx.open(ck.srs, zpack.data_ptr(), [z_c.shape[0]], stride, zw_(zeta * int(g) % r), zw_(v), device=True)
-        W_zw = kzg._points(xy, inf)[0]
+        alg.ctx.open_device_async(ck.srs, zpack.data_ptr(), [z_c.shape[0]], stride, zw_(zeta * int(g) % r), zw_(v), *o2)
+        alg.ctx.commit_flush()
+        W_z = kzg._points(o1[0], o1[1])[0]
+        W_zw = kzg._points(o2[0], o2[1])[0]
         return {"commitments": dict(zip(("a", "b", "c"), wire_comms), z=z_comm,
                                     t_lo=t_comms[0], t_mid=t_comms[1], t_hi=t_comms[2]),
                 "evaluations": evF,

@@ -6,8 +6,8 @@
 // Division by (X - z) is synthetic division: with S_j = sum_{i>=j} c_i z^(i-j)
 // (suffix Horner values, S_j = c_j + z*S_{j+1}) the quotient is q_{j-1} = S_j for
 // j >= 1 and combined(z) = S_0.  The first-order recurrence is evaluated in
-// parallel by chunking: chunks of LC coefficients are collapsed bottom-up into
-// one value each (a polynomial in z^LC of 1/LC the length; repeated until <= LC
+// parallel by chunking: chunks of SC coefficients are collapsed bottom-up into
+// one value each (a polynomial in z^SC of 1/SC the length; repeated until <= SC
 // values remain), the short top level is solved directly, and the suffix values
 // are pushed back down, each thread re-walking its chunk from the carry above.
 // Cost: ~2 Montgomery multiplications per coefficient, all data HBM-streamed
@@ -25,7 +25,15 @@ namespace kzg {
 
 namespace {
 
-constexpr uint32_t LC = 32;       // coefficients per chunk
+constexpr uint32_t LC = 32;       // elements per thread of the vector primitives (batch inversion, powers, prefix product)
+// Chunk of the suffix-Horner scans (open, poly_eval): their cost is the DEPENDENT chain of SC multiply-adds per
+// thread, not bandwidth -- measured at 2^20, k = 6: 151 us with chunks of 32, 129 with 16, 114 with 8 (more, shorter
+// levels; the batch inversion above wants the opposite, hence two constants).
+#ifndef KZG_POLY_SC_LOG
+#define KZG_POLY_SC_LOG 3
+#endif
+constexpr uint32_t SC_LOG = KZG_POLY_SC_LOG;
+constexpr uint32_t SC = 1u << SC_LOG;
 constexpr uint32_t MAXK = 64;     // polynomials per open()
 
 constexpr int FRN = 9;            // both scalar fields: 9 x 29-bit limbs
@@ -85,14 +93,14 @@ __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
   store_words<F>(out + (size_t)t * 8, acc);
 }
 
-// bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*LC)
+// bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*SC)
 template <class F, bool WORDS_IN>
 __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* h) {
   using Fd = Field<F>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j0 = t * LC;
+  const uint32_t j0 = t * SC;
   if (j0 >= m) return;
-  const uint32_t j1 = min(j0 + LC, m);
+  const uint32_t j1 = min(j0 + SC, m);
   const Fe<F> z = load_limbs<F>(zpow.l);
   Fe<F> acc = Fd::zero();
   for (uint32_t j = j1; j-- > j0;) {
@@ -102,7 +110,7 @@ __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, ui
   store_limbs<F>(h + (size_t)t * F::N, acc);
 }
 
-// top level (m <= LC): S[j] = c_j + z*S[j+1], S[m] = 0; one thread
+// top level (m <= SC): S[j] = c_j + z*S[j+1], S[m] = 0; one thread
 template <class F>
 __global__ void top_suffix_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* S) {
   using Fd = Field<F>;
@@ -123,9 +131,9 @@ __global__ void chunk_fill_kernel(const uint32_t* in, uint32_t m, FrArg zpow, co
                                   uint32_t* S_out, uint32_t* quot, uint32_t* eval_out) {
   using Fd = Field<F>;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j0 = t * LC;
+  const uint32_t j0 = t * SC;
   if (j0 >= m) return;
-  const uint32_t j1 = min(j0 + LC, m);
+  const uint32_t j1 = min(j0 + SC, m);
   const Fe<F> z = load_limbs<F>(zpow.l);
   Fe<F> acc = load_limbs<F>(S_up + (size_t)(t + 1) * F::N);
   if (!FINAL && t == 0 && j1 == m) { /* single chunk: nothing above */ }
@@ -193,17 +201,16 @@ template <class F>
 int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out, bool sync = true) {
   using Fd = Field<F>;
   std::vector<uint32_t> m{(uint32_t)n};
-  while (m.back() > LC) m.push_back((m.back() + LC - 1) / LC);
+  while (m.back() > SC) m.push_back((m.back() + SC - 1) / SC);
   const size_t nl = m.size();
-  std::vector<FrArg> zp(nl);                              // z^(LC^l), Montgomery form, passed by value
+  std::vector<FrArg> zp(nl);                              // z^(SC^l), Montgomery form, passed by value
   {
     Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
     for (size_t l = 0; l < nl; ++l) {
       memcpy(zp[l].l, t.l, F::N * 4);
-      for (int q = 0; q < 5; ++q) t = Fd::mul(t, t);        // ^32 = ^LC
+      for (uint32_t q = 0; q < SC_LOG; ++q) t = Fd::mul(t, t);        // ^(2^SC_LOG) = ^SC
     }
   }
-  static_assert(LC == 32, "the power update assumes LC = 2^5");
   size_t hl_total = 0, sl_total = 0;
   for (size_t l = 1; l < nl; ++l) { hl_total += m[l]; sl_total += m[l] + 1; }
   int rc;
@@ -223,7 +230,7 @@ int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t*
     for (size_t l = 1; l < nl; ++l) { hptr[l] = hp; hp += (size_t)m[l] * F::N; sptr[l] = sp; sp += (size_t)(m[l] + 1) * F::N; }
   }
   if (nl == 1) {
-    // n <= LC: a single chunk; its carry is zero.  Use a one-entry zero suffix array.
+    // n <= SC: a single chunk; its carry is zero.  Use a one-entry zero suffix array.
     KZG_HIP(c, hipMemsetAsync(d_S, 0, 2 * F::N * 4, c->stream));
     hipLaunchKernelGGL((chunk_fill_kernel<F, true>), dim3(1), dim3(64), 0, c->stream, d_comb, m[0], zpow(0), d_S,
                        (uint32_t*)nullptr, d_quot, d_eval);
@@ -609,14 +616,14 @@ int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, ui
   if (n == 0) return KZG_OK;
   if (n >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "vector too long");
   std::vector<uint32_t> m{(uint32_t)n};
-  while (m.back() > 1) m.push_back((m.back() + LC - 1) / LC);
+  while (m.back() > 1) m.push_back((m.back() + SC - 1) / SC);
   const size_t nl = m.size();
-  std::vector<FrArg> zp(nl);                              // z^(LC^l), passed to the kernels by value
+  std::vector<FrArg> zp(nl);                              // z^(SC^l), passed to the kernels by value
   {
     Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
     for (size_t l = 0; l < nl; ++l) {
       memcpy(zp[l].l, t.l, F::N * 4);
-      for (int q = 0; q < 5; ++q) t = Fd::mul(t, t);
+      for (uint32_t q = 0; q < SC_LOG; ++q) t = Fd::mul(t, t);
     }
   }
   size_t total = 0;

@@ -30,7 +30,7 @@ struct NttDomain {
   uint32_t* d_twA = nullptr;     // [2^(log_n-h)][9]  (w^(2^h))^u  (x n^-1 when inverse)
   uint32_t* d_twB = nullptr;     // [2^h][9]          w^l
   uint32_t* d_scale = nullptr;   // [9] n^-1 for a single-pass inverse transform; null: the last pass only reduces
-  uint32_t* d_twist = nullptr;   // [n][9] w^(t*v) for two-pass sizes (row t of N2 entries)
+  uint32_t* d_twist = nullptr;   // [n][9] w^(t*v) for two-pass sizes (row t of N2 entries); only with KZG_NTT_TWIST_TABLE=1
   uint64_t last_use = 0;
 };
 

@@ -10,7 +10,7 @@
 //
 // Decomposition (n = N1*N2, x viewed as an N1 x N2 row-major matrix):
 //   pass 1: N1-point transforms down the columns (root w^N2), then element
-//           (t, v) is multiplied by w^(t*v);
+//           (t, v) is multiplied by w^(t*v) (product of two small-table entries);
 //   pass 2: N2-point transforms along the rows (root w^N1); row t, output
 //           index b lands at out[b*N1 + t].
 // The twist w^(t*v) is an exact field identity for every w (the t-dependent
@@ -53,6 +53,8 @@ struct NttPassArgs {
   uint32_t* dst;
   const uint32_t* stage;   // stage twiddles (Montgomery), root order 2^kmax
   const uint32_t* twist;   // pass 1: table of w^(pos*col), [line length][row pitch] entries, or nullptr
+  const uint32_t* twA;     // default: w^(pos*col) = twA[e >> h] * twB[e & (2^h - 1)], e = pos*col, from the two small
+  const uint32_t* twB;     //   factor tables (build_domain); `twist` is only set under KZG_NTT_TWIST_TABLE=1
   const uint32_t* scale;   // last pass: final multiplier (Montgomery 1 or n^-1), or nullptr
   uint64_t twist_pitch;    // entries per twist-table row (= N2)
   uint32_t k;              // log2 line length
@@ -194,6 +196,11 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
       // weak-normal (< 2p < 2^256) is enough between the passes: the next pass starts its lazy
       // levels from it (2p + 4p per level stays below the 64p that reduce_wide accepts)
       x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
+    } else if (a.twA) {
+      const uint64_t e = (uint64_t)pos * (a.col_base + tile * C + line);
+      const Fe<F> tw = Fd::reduce(Fd::mul(glb_get_limbs<F>(a.twA + (size_t)(e >> a.h) * F::N),
+                                          glb_get_limbs<F>(a.twB + (size_t)(e & ((1ull << a.h) - 1)) * F::N)));
+      x = Fd::mul(x, tw);
     } else if (a.scale) {
       x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.scale)));      // single-pass inverse: n^-1
     } else {
@@ -279,7 +286,13 @@ int build_domain(Ctx* c, NttDomain& d) {
     KZG_HIP(c, hipStreamSynchronize(c->stream));
   }
   KZG_HIP(c, hipFree(d_tmp));
-  if (two_pass) {   // full twist table (one multiplication per element between the passes)
+  // The twist w^(t*v) comes from the two factor tables (e = t*v = hi * 2^h + lo: twA[hi] * twB[lo], 2 x 2^10 entries at
+  // 2^20) -- one more multiplication per element than a full [N1][N2] table, but measured at the same time (112-115 us
+  // either way at 2^20: the table's 36 MiB of reads per transform stalled as much as the multiplication costs) with
+  // half the reads (67.9 vs 135.8 MB per transform, rocprofv3 FETCH_SIZE) and no 36 MiB (2^24: 576 MiB) per cached
+  // domain.  KZG_NTT_TWIST_TABLE=1 brings the full table back (A/B).
+  static const bool twist_table = [] { const char* e = getenv("KZG_NTT_TWIST_TABLE"); return e && atoi(e) != 0; }();
+  if (two_pass && twist_table) {   // full twist table (one multiplication per element between the passes)
     const uint32_t k2 = log_n - (log_n + 1) / 2;
     const uint64_t n = 1ull << log_n;
     KZG_HIP(c, hipMalloc(&d.d_twist, (size_t)n * F::N * 4));
@@ -354,6 +367,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     a.ld_shift = a.st_shift = 31;
     a.pair_tiles = (logC < 2 && ((N2 >> logC) % (8u << (2 - logC)) == 0)) ? 2 - logC : 0;
     a.src = d_data; a.dst = scratch; a.stage = d.d_stage; a.twist = d.d_twist; a.twist_pitch = N2;
+    a.twA = d.d_twist ? nullptr : d.d_twA; a.twB = d.d_twB;
     a.scale = nullptr;
     a.k = k1; a.logC = logC; a.kmax = d.kmax; a.h = d.h; a.c_fast_load = 1; a.c_fast_store = 1; a.col_base = 0;
     a.ld_line = 1; a.ld_pos = N2; a.tile_ld = 1ull << logC;
@@ -414,6 +428,7 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
   if (!rows_pass) {
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, lc);
     a.twist = dom->d_twist; a.twist_pitch = N2; a.scale = nullptr; a.col_base = col_base;
+    a.twA = dom->d_twist ? nullptr : dom->d_twA; a.twB = dom->d_twB; a.h = dom->h;
     a.k = k1; a.logC = logC; a.c_fast_load = 1; a.c_fast_store = 1;
     a.ld_line = 1; a.ld_pos = count; a.tile_ld = 1ull << logC;
     a.st_line = 1; a.st_pos = count; a.tile_st = 1ull << logC;

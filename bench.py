@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SHADER_PEAK_MHZ = 2400.0
 VALU_PEAK_GINSTR = 1024 * 2.4 / 4   # wave64 VALU instructions/ns: 1024 SIMDs x 2.4 GHz / 4 cycles per instruction
 R_BLS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -589,6 +590,7 @@ def main(argv=None):
     elapsed = env.max_over_ranks(elapsed)
     spans_main = {name: ctx.prof_read(name) for name in
                   ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
+    mhz_pipelined = ctx.prof_read("msm_accumulate_shader_mhz")[0]
 
     # ---- the timed loop's own results, checked (outside the timed region): the coefficients of the last
     # step are still in its work buffer; commit(ck, p) must be p(tau) G1 for each of its B polynomials,
@@ -625,6 +627,7 @@ def main(argv=None):
         ctx.commit_flush()
     env.barrier()
     acc_alone = ctx.prof_read("msm_accumulate")
+    mhz_alone = ctx.prof_read("msm_accumulate_shader_mhz")[0]
     spans_alone = {name: ctx.prof_read(name) for name in
                    ("msm_partition1", "msm_partition2", "msm_order", "msm_accumulate", "msm_finalize", "msm_reduce")}
     ctx.prof_enable(False)
@@ -726,6 +729,14 @@ def main(argv=None):
                                            "hbm_achieved_GBps_from_traffic": (ent["hbm_bytes"] / dur_s / 1e9)
                                            if ent.get("hbm_bytes") else None,
                                            "source": cj.get("source")}
+                    if key == "roofline" and mhz_alone > 0:
+                        # the shader clock is power-managed: the kernel reports the one it actually ran at
+                        # (s_memtime / s_memrealtime, measured live), and the issue peak at THAT clock
+                        peak_at_clock = VALU_PEAK_GINSTR * mhz_alone / SHADER_PEAK_MHZ
+                        out[key]["limiter"].update({"shader_mhz_isolated": mhz_alone,
+                                                    "shader_mhz_pipelined": mhz_pipelined or None,
+                                                    "peak_at_measured_clock": peak_at_clock,
+                                                    "frac_at_measured_clock": ach / peak_at_clock})
         out.update(sections)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.curve, log_n, omega)

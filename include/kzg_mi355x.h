@@ -218,7 +218,10 @@ int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4
  * When enabled, the library brackets its kernels with HIP events on the stream each one runs on.
  * Span names: "ntt_pass", "msm_partition1", "msm_partition2", "msm_order", "msm_accumulate",
  * "msm_finalize", "msm_reduce", "open_poly".  kzg_prof_read synchronises the stream and returns
- * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset. */
+ * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset.
+ * One name is not a span: "msm_accumulate_shader_mhz" returns (in *total_ms) the shader clock in MHz
+ * the accumulate kernel ran at since the last reset -- s_memtime over s_memrealtime ticks of its
+ * first wave -- and *count = 1 when a launch has reported, 0 otherwise. */
 int kzg_prof_enable(kzg_ctx* ctx, int on);
 int kzg_prof_reset(kzg_ctx* ctx);
 int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* count);

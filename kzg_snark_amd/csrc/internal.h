@@ -64,6 +64,7 @@ struct Ctx {
   void* msm_work = nullptr;               // MsmWork (msm.hip)
   bool prof_on = false;
   std::vector<ProfSpan> prof;
+  unsigned long long* clk_probe = nullptr;   // [2] shader-clock / 100 MHz ticks spent in msm_accumulate (profiling only)
   std::vector<hipStream_t> aux_streams;   // commit pipeline
   std::vector<hipEvent_t> aux_events;
 };

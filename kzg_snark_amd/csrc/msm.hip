@@ -319,7 +319,7 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
                                                              const uint32_t* bstart, const uint32_t* order,
                                                              const uint32_t* slice_off, uint32_t* partials,
                                                              uint32_t* buckets, uint32_t* chunk_counter,
-                                                             const uint32_t* chunk_rank) {
+                                                             const uint32_t* chunk_rank, unsigned long long* clk) {
   using F = typename C::Fp;
   using Fd = Field<F>;
   using St = RecStage<C>;
@@ -328,11 +328,21 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
   const uint32_t total = slice_off[NB];
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t* stage = stage_all + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * St::WAVE_WORDS);
+  // profiling only (clk is null otherwise): wave 0 of workgroup 0 reports the shader clock it ran at, as the
+  // ratio of s_memtime (shader clock) to s_memrealtime (100 MHz) ticks over its lifetime
+  const bool probe = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+  const long long c0 = probe ? clock64() : 0, w0 = probe ? wall_clock64() : 0;
   for (;;) {
     uint32_t chunk = 0;
     if (lane == 0) chunk = atomicAdd(chunk_counter, 1u);
     chunk = __builtin_amdgcn_readfirstlane(chunk);
-    if ((uint64_t)chunk * 64 >= total) break;          // every wave reaches this: the counter only grows
+    if ((uint64_t)chunk * 64 >= total) {               // every wave reaches this: the counter only grows
+      if (probe && lane == 0) {
+        atomicAdd(clk, (unsigned long long)(clock64() - c0));
+        atomicAdd(clk + 1, (unsigned long long)(wall_clock64() - w0));
+      }
+      break;
+    }
     const uint32_t t = chunk * 64 + lane;
     if (t >= total) continue;
     // rank of the bucket of slice t: largest r with slice_off[r] <= t.  Every non-empty bucket has a
@@ -814,7 +824,8 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
     hipLaunchKernelGGL((msm_accumulate_kernel<C, WB>), dim3(std::min(w->acc_blocks, (max_slices + 127) / 128)),
                        dim3(128), 0, sa, s->recs, vals, bstart, order, slice_off,
                        static_cast<uint32_t*>(sl.partials.p), static_cast<uint32_t*>(sl.buckets.p),
-                       static_cast<uint32_t*>(sl.counter.p), static_cast<const uint32_t*>(sl.chunk_rank.p));
+                       static_cast<uint32_t*>(sl.counter.p), static_cast<const uint32_t*>(sl.chunk_rank.p),
+                       c->prof_on ? c->clk_probe : nullptr);
   }
   KZG_HIP(c, hipGetLastError());
   KZG_HIP(c, hipEventRecord(sl.ev_a, sa));

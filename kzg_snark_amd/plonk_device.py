@@ -108,13 +108,19 @@ class DeviceAlgebra:
         return t
 
     def set_entries(self, t, updates):
-        """t[i] = (t[i] + delta) mod r for a handful of (i, delta) pairs (blinding terms)."""
-        self.ctx.synchronize()
-        for i, delta in updates:
-            cur = _native.limbs_to_ints(t[i:i + 1].cpu().numpy().view(np.uint64))[0]
-            row = _native.int_to_words((cur + int(delta)) % self.r).view(np.int64)
-            with torch.cuda.stream(self.stream):
-                t[i] = torch.from_numpy(row).to(self.dev)
+        """t[i] = (t[i] + delta) mod r for a handful of (i, delta) pairs (blinding terms), on the device: the
+        deltas travel in one pinned, stream-ordered copy and each entry is a one-element field addition, so the
+        host never waits for the work queued before it."""
+        if not updates:
+            return
+        rows = np.stack([_native.int_to_words(int(d) % self.r) for _, d in updates]).view(np.int64)
+        host = torch.from_numpy(rows).pin_memory()
+        with torch.cuda.stream(self.stream):
+            dl = host.to(self.dev, non_blocking=True)          # the pinned block is recycled only after the copy ran
+        for j, (i, _) in enumerate(updates):
+            assert 0 <= i < t.shape[0]
+            p = t.data_ptr() + 32 * i
+            self.ctx.vec_op("add", 1, p, dl.data_ptr() + 32 * j, p)
 
 
 class DeviceIndexer:
@@ -147,6 +153,37 @@ class DeviceProver:
     def __init__(self, curve_type="bls12_381", alg=None):
         self.kzg = KZG(curve_type)
         self.alg = alg or DeviceAlgebra(curve_type)
+
+    def _domain_constants(self, n, g):
+        """Vectors that depend only on the evaluation domain (not on the circuit or the witness), built once per
+        domain size and kept on the device: 1, g^i on H; on the coset K*H' of the size-4n subgroup the points x,
+        1/Z_H(x) and L1(x) = Z_H(x) / (n (x - 1))."""
+        key = (n, int(g))
+        cache = self.__dict__.setdefault("_dom_cache", {})
+        if key not in cache:
+            alg, Fq = self.alg, self.kzg.Fq
+            r = self.kzg.curve_order
+            N4 = 4 * n
+            w4, K = int(Fq.root_of_unity(N4)), int(Fq.multiplicative_generator())
+            ones = alg.const(n, 1)
+            ones4 = alg.const(N4, 1)
+            xs = alg.mul_powers(ones4, w4, K)                                     # the coset points
+            xn = alg.mul_powers(ones4, pow(w4, n, r), pow(K, n, r))               # x^n: four distinct values
+            zh = alg.sub(xn, ones4)
+            cache.clear()                                                          # one domain at a time (N4-sized vectors)
+            cache[key] = {"ones": ones, "idH": alg.mul_powers(ones, g), "ones4": ones4, "xs": xs,
+                          "zh_inv": alg.inverse(zh), "w4": w4, "K": K, "e0": alg.const(1, 1),
+                          "l1": alg.mul(zh, alg.inverse(alg.lincomb(N4, [(n, xs), (-n, ones4)])))}
+        return cache[key]
+
+    def _circuit_cosets(self, ipk, on_coset):
+        """Coset evaluations of the eight preprocessed polynomials: fixed per circuit, so they live with the
+        proving key (4n elements each) instead of being re-transformed for every proof."""
+        cache = ipk.get("_coset_evals")
+        if cache is None:
+            cache = ipk["_coset_evals"] = {k: on_coset(ipk["coeffs"][k]) for k in
+                                           ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3")}
+        return cache
 
     def _commit(self, ck, tensors):
         alg = self.alg
@@ -188,8 +225,8 @@ class DeviceProver:
         assert full_limbs.shape[0] == 3 * n
         b = [int(Fq.random_element()) for _ in range(11)] if blinders is None else [int(v) % r for v in blinders]
         assert len(b) == 11
-        ones = alg.const(n, 1)
-        idH = alg.mul_powers(ones, g)                                         # g^i
+        D = self._domain_constants(n, g)
+        ones, idH = D["ones"], D["idH"]                                       # 1 and g^i on H
 
         # round 1
         vals = [alg.upload_limbs(full_limbs[i * n:(i + 1) * n]) for i in range(3)]
@@ -215,8 +252,7 @@ class DeviceProver:
 
         # round 3: quotient on the coset K * H', |H'| = 4n
         N4 = 4 * n
-        w4 = int(Fq.root_of_unity(N4))
-        K = int(Fq.multiplicative_generator())
+        w4, K = D["w4"], D["K"]
 
         def on_coset(coeffs):
             return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
@@ -226,10 +262,8 @@ class DeviceProver:
             pi[:len(x)] = alg.upload([(-int(v)) % r for v in x])
         PI_c = alg.ntt(pi, g, True)
         E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("z", z_c), ("PI", PI_c))}
-        for k in ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3"):
-            E[k] = on_coset(C[k])
-        ones4 = alg.const(N4, 1)
-        xs = alg.mul_powers(ones4, w4, K)                                     # the coset points
+        E.update(self._circuit_cosets(ipk, on_coset))
+        ones4, xs = D["ones4"], D["xs"]                                       # 1 and the coset points
         zw = torch.roll(E["z"], shifts=-4, dims=0).contiguous()              # z(g * x): g = w4^4
         gate = alg.add(alg.add(alg.mul(alg.mul(E["a"], E["b"]), E["qM"]), alg.mul(E["a"], E["qL"])),
                        alg.add(alg.mul(E["b"], E["qR"]), alg.mul(E["c"], E["qO"])))
@@ -241,16 +275,17 @@ class DeviceProver:
             p1 = f1 if p1 is None else alg.mul(p1, f1)
             p2 = f2 if p2 is None else alg.mul(p2, f2)
         perm = alg.sub(alg.mul(p1, E["z"]), alg.mul(p2, zw))
-        # Z_H(x) = x^n - 1 and L1(x) = Z_H(x) / (n (x - 1)) on the coset
-        xn = alg.mul_powers(ones4, pow(w4, n, r), pow(K, n, r))                # x^n: four distinct values
-        zh = alg.sub(xn, ones4)
-        l1 = alg.mul(zh, alg.inverse(alg.lincomb(N4, [(n, xs), (-n, ones4)])))
-        l1t = alg.mul(alg.sub(E["z"], ones4), l1)
+        # Z_H(x) = x^n - 1 and L1(x) = Z_H(x) / (n (x - 1)) on the coset: domain constants
+        l1t = alg.mul(alg.sub(E["z"], ones4), D["l1"])
         numer = alg.lincomb(N4, [(1, gate), (alpha, perm), (alpha * alpha, l1t)])
-        t_ev = alg.mul(numer, alg.inverse(zh))
+        t_ev = alg.mul(numer, D["zh_inv"])
         t_c = alg.mul_powers(alg.ntt(t_ev, w4, True), pow(K, -1, r))          # back to coefficients
-        tail = alg.download(t_c[3 * n + 6:3 * n + 6 + 64])
-        assert not any(tail), "constraint system is not satisfied (quotient has a remainder)"
+        # the quotient must have degree <= 3n + 5: its tail is fetched behind the work queued so far and
+        # looked at once the round's commitments have come back (no extra wait)
+        tail = t_c[3 * n + 6:3 * n + 6 + 64]
+        tail_host = torch.empty(tuple(tail.shape), dtype=torch.int64).pin_memory()
+        with torch.cuda.stream(alg.stream):
+            tail_host.copy_(tail, non_blocking=True)
         t_lo = alg.padded(t_c[:n], n + 1)
         t_mid = alg.padded(t_c[n:2 * n], n + 1)
         t_hi = t_c[2 * n:3 * n + 6].clone()
@@ -258,6 +293,7 @@ class DeviceProver:
         alg.set_entries(t_mid, [(0, -b[9]), (n, b[10])])
         alg.set_entries(t_hi, [(0, -b[10])])
         t_comms, _ = self._commit(ck, [t_lo, t_mid, t_hi])
+        assert not bool(tail_host.any()), "constraint system is not satisfied (quotient has a remainder)"
         tr.append_message("round3-commitments", t_comms)
         zeta = int(tr.get_challenge("zeta"))
 
@@ -276,7 +312,7 @@ class DeviceProver:
         PIz = alg.eval(PI_c, zeta)
         f1 = (za + beta * zeta + gamma) * (zb + beta * int(k1) * zeta + gamma) * (zc + beta * int(k2) * zeta + gamma) % r
         f2 = (za + beta * s1 + gamma) * (zb + beta * s2 + gamma) * zo % r
-        e0 = alg.const(1, 1)
+        e0 = D["e0"]
         const = (PIz - alpha * f2 * (zc + gamma) - alpha * alpha * L1z) % r
         r_c = alg.lincomb(n + 6, [
             (za * zb, C["qM"]), (za, C["qL"]), (zb, C["qR"]), (zc, C["qO"]), (1, C["qC"]), (const, e0),

@@ -47,6 +47,18 @@ class DeviceAlgebra:
         with torch.cuda.stream(self.stream):
             return torch.from_numpy(arr.view(np.int64)).to(self.dev, non_blocking=False)
 
+    def upload_parts(self, n, parts):
+        """Concatenation of uint64[k_j, 4] arrays (sum k_j = n) as one device vector."""
+        out = torch.empty((n, 4), dtype=torch.int64, device=self.dev)
+        at = 0
+        with torch.cuda.stream(self.stream):
+            for a in parts:
+                a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+                out[at:at + a.shape[0]].copy_(torch.from_numpy(a.view(np.int64)))
+                at += a.shape[0]
+        assert at == n
+        return out
+
     def download(self, t, count=None):
         self.ctx.synchronize()
         a = t[:count] if count is not None else t
@@ -186,11 +198,24 @@ class DeviceProver:
         return cache
 
     def _commit(self, ck, tensors):
+        return self._commit_end(self._commit_begin(ck, tensors)), None
+
+    def _commit_begin(self, ck, tensors):
+        """Queue the commitments of a round on the library's pipeline and return at once: whatever the prover
+        enqueues next that does not need the round's challenge runs beside the MSMs (they are instruction-issue
+        bound, the vector work is HBM-bound)."""
         alg = self.alg
         stride = max(t.shape[0] for t in tensors)
         pack = torch.stack([alg.padded(t, stride) for t in tensors]).contiguous()
-        xy, inf = alg.ctx.commit_device(ck.srs, pack.data_ptr(), [t.shape[0] for t in tensors], stride)
-        return self.kzg._points(xy, inf), pack
+        xy = np.zeros((len(tensors), 2 * alg.ctx.fp_limbs), dtype=np.uint64)
+        inf = np.zeros(len(tensors), dtype=np.uint8)
+        alg.ctx.commit_device_async(ck.srs, pack.data_ptr(), [t.shape[0] for t in tensors], stride, xy, inf)
+        return pack, xy, inf
+
+    def _commit_end(self, handle):
+        _, xy, inf = handle
+        self.alg.ctx.commit_flush()
+        return self.kzg._points(xy, inf)
 
     def _blind(self, coeffs, n, blinders):
         """coeffs (length n) + (b_k X^k + ... + b_0) * (X^n - 1): length n + len(blinders)."""
@@ -217,22 +242,51 @@ class DeviceProver:
         dom.Fq, dom.n, dom.g = Fq, n, g
         tr = Transcript("plonk-proof", Fq)
         tr.append_message("public-inputs", x)
+        x_limbs = _native.ints_to_limbs([int(v) % r for v in x]).reshape(-1, 4)
         if isinstance(w, np.ndarray):                # witness already in limb form: no per-element Python work
-            full_limbs = np.concatenate([_native.ints_to_limbs([int(v) % r for v in x]),
-                                         np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)])
+            w_limbs = np.ascontiguousarray(w, dtype=np.uint64).reshape(-1, 4)
         else:
-            full_limbs = _native.ints_to_limbs([int(v) % r for v in list(x) + list(w)])
-        assert full_limbs.shape[0] == 3 * n
+            w_limbs = _native.ints_to_limbs([int(v) % r for v in w]).reshape(-1, 4)
+        nx = x_limbs.shape[0]
+        assert nx + w_limbs.shape[0] == 3 * n
+
+        def column(i):
+            """rows [i n, (i+1) n) of x ++ w, uploaded piecewise (no host-side copy of the 96 n bytes)."""
+            lo, hi = i * n, (i + 1) * n
+            parts = []
+            if lo < nx:
+                parts.append(x_limbs[lo:min(hi, nx)])
+            if hi > nx:
+                parts.append(w_limbs[max(lo, nx) - nx:hi - nx])
+            return alg.upload_parts(n, parts)
         b = [int(Fq.random_element()) for _ in range(11)] if blinders is None else [int(v) % r for v in blinders]
         assert len(b) == 11
         D = self._domain_constants(n, g)
         ones, idH = D["ones"], D["idH"]                                       # 1 and g^i on H
 
         # round 1
-        vals = [alg.upload_limbs(full_limbs[i * n:(i + 1) * n]) for i in range(3)]
+        vals = [column(i) for i in range(3)]
         wires = [self._blind(alg.ntt(v.clone(), g, True), n, [b[2 * i + 1], b[2 * i]]) for i, v in enumerate(vals)]
         a_c, b_c, c_c = wires
-        wire_comms, _ = self._commit(ck, wires)
+        pi = alg.zeros(n)                                                    # PI values: -x_i on the first rows
+        if len(x):
+            pi[:len(x)] = alg.upload([(-int(v)) % r for v in x])
+        h1 = self._commit_begin(ck, wires)
+        # queued behind the round-1 MSMs, needing no challenge: the wires and PI on the coset K * H', |H'| = 4n,
+        # and the gate constraint
+        N4 = 4 * n
+        w4, K = D["w4"], D["K"]
+
+        def on_coset(coeffs):
+            return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
+
+        PI_c = alg.ntt(pi, g, True)
+        E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("PI", PI_c))}
+        E.update(self._circuit_cosets(ipk, on_coset))
+        gate = alg.add(alg.add(alg.mul(alg.mul(E["a"], E["b"]), E["qM"]), alg.mul(E["a"], E["qL"])),
+                       alg.add(alg.mul(E["b"], E["qR"]), alg.mul(E["c"], E["qO"])))
+        gate = alg.add(gate, alg.add(E["PI"], E["qC"]))
+        wire_comms = self._commit_end(h1)
         tr.append_message("round1-commitments", wire_comms)
         beta, gamma = int(tr.get_challenge("beta")), int(tr.get_challenge("gamma"))
 
@@ -246,28 +300,11 @@ class DeviceProver:
             den = fd if den is None else alg.mul(den, fd)
         z_vals = alg.prefix_product(alg.mul(num, alg.inverse(den)))
         z_c = self._blind(alg.ntt(z_vals, g, True), n, [b[8], b[7], b[6]])
-        z_comm = self._commit(ck, [z_c])[0][0]
-        tr.append_message("round2-commitment", z_comm)
-        alpha = int(tr.get_challenge("alpha"))
-
-        # round 3: quotient on the coset K * H', |H'| = 4n
-        N4 = 4 * n
-        w4, K = D["w4"], D["K"]
-
-        def on_coset(coeffs):
-            return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
-
-        pi = alg.zeros(n)                                                    # PI values: -x_i on the first rows
-        if len(x):
-            pi[:len(x)] = alg.upload([(-int(v)) % r for v in x])
-        PI_c = alg.ntt(pi, g, True)
-        E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("z", z_c), ("PI", PI_c))}
-        E.update(self._circuit_cosets(ipk, on_coset))
+        h2 = self._commit_begin(ck, [z_c])
+        # queued behind the round-2 MSM: everything of the quotient that needs beta and gamma but not alpha
+        E["z"] = on_coset(z_c)
         ones4, xs = D["ones4"], D["xs"]                                       # 1 and the coset points
         zw = torch.roll(E["z"], shifts=-4, dims=0).contiguous()              # z(g * x): g = w4^4
-        gate = alg.add(alg.add(alg.mul(alg.mul(E["a"], E["b"]), E["qM"]), alg.mul(E["a"], E["qL"])),
-                       alg.add(alg.mul(E["b"], E["qR"]), alg.mul(E["c"], E["qO"])))
-        gate = alg.add(gate, alg.add(E["PI"], E["qC"]))
         p1 = p2 = None
         for key, shift, sig in (("a", 1, "S_sigma1"), ("b", int(k1), "S_sigma2"), ("c", int(k2), "S_sigma3")):
             f1 = alg.lincomb(N4, [(1, E[key]), (beta * shift, xs), (gamma, ones4)])
@@ -277,6 +314,11 @@ class DeviceProver:
         perm = alg.sub(alg.mul(p1, E["z"]), alg.mul(p2, zw))
         # Z_H(x) = x^n - 1 and L1(x) = Z_H(x) / (n (x - 1)) on the coset: domain constants
         l1t = alg.mul(alg.sub(E["z"], ones4), D["l1"])
+        z_comm = self._commit_end(h2)[0]
+        tr.append_message("round2-commitment", z_comm)
+        alpha = int(tr.get_challenge("alpha"))
+
+        # round 3: combine with alpha, divide by Z_H, back to coefficients
         numer = alg.lincomb(N4, [(1, gate), (alpha, perm), (alpha * alpha, l1t)])
         t_ev = alg.mul(numer, D["zh_inv"])
         t_c = alg.mul_powers(alg.ntt(t_ev, w4, True), pow(K, -1, r))          # back to coefficients

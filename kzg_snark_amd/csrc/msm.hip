@@ -403,8 +403,9 @@ __global__ __launch_bounds__(128, 3) void msm_accumulate_kernel(const uint32_t* 
   }
 }
 
-// The reduce-stage kernels run beside the persistent accumulate kernel, which holds 2 waves x 168
-// VGPRs of every SIMD: 176 VGPRs are left of the 512, i.e. the 168 of a 3-waves-per-SIMD budget.
+// The reduce-stage kernels run beside the persistent accumulate kernel, which holds 2 waves x 160
+// VGPRs (153 used, BLS12-381) of every SIMD: 192 of the 512 are left, so the reduce kernels are
+// compiled to the 168 of a 3-waves-per-SIMD budget and one of their waves fits every SIMD.
 #ifndef KZG_SIDE_WAVES
 #define KZG_SIDE_WAVES 3
 #endif
@@ -707,7 +708,7 @@ int srs_export(Ctx* c, const Srs* s, size_t start, size_t count, uint64_t* xy, u
 //   A  accumulate  the mixed-addition kernel                        (ALU-bound, persistent)
 //   B  reduce      finalize, row/column sums, bit planes, copy-out  (latency-bound)
 // prep(p+1), accumulate(p) and reduce(p-1) run concurrently ON THE SAME SIMDs: A holds 2 waves x
-// 168 VGPRs of each, P and B workgroups are sized to fit into what is left.  The context's stream only
+// 160 VGPRs of each, P and B workgroups are sized to fit into what is left.  The context's stream only
 // carries ordering: P waits for everything enqueued on it before the call (the scalars), and it
 // waits for P to have consumed the scalars, so later work on the context's stream (the next NTT)
 // can neither race with prep nor queue behind accumulate.  Every buffer belongs to a slot; the

@@ -26,9 +26,7 @@ class Domain:
         self.Fq = Fq
         self.n = 1 << max(0, (n_gates - 1).bit_length())
         self.g = Fq.root_of_unity(self.n)
-        self.H = [Fq(1)]
-        for _ in range(self.n - 1):
-            self.H.append(self.H[-1] * self.g)
+        self._H = None                           # the n points themselves: built when first asked for (the verifier never does)
         n, ks = self.n, []
         cand = 2
         while len(ks) < 2:
@@ -37,6 +35,15 @@ class Domain:
                 ks.append(k)
             cand += 1
         self.k1, self.k2 = ks
+
+    @property
+    def H(self):
+        if self._H is None:
+            H = [self.Fq(1)]
+            for _ in range(self.n - 1):
+                H.append(H[-1] * self.g)
+            self._H = H
+        return self._H
 
     def sigma_star(self, perm):
         """Position j in [0, 3n) -> its label in H, k1*H or k2*H; composed with the permutation."""
@@ -50,6 +57,21 @@ class Domain:
     def lagrange_1_at(self, x):
         n = self.n
         return (x ** n - 1) / (self.Fq(n) * (x - 1))
+
+    def public_input_at(self, x, zeta):
+        """PI(zeta) = -sum_i x_i L_i(zeta) with L_i(X) = g^i (X^n - 1) / (n (X - g^i)): what the verifier needs
+        (plonk/verifier.py evaluates the interpolated PI polynomial; same value), in O(len(x)) field operations
+        instead of an n-point interpolation."""
+        Fq, n = self.Fq, self.n
+        zeta = Fq(zeta)
+        zh = zeta ** n - 1
+        acc, gi = Fq(0), Fq(1)
+        for v in x:
+            if zeta == gi:                       # zeta on the domain: L_i(zeta) = 1, every other basis polynomial vanishes
+                return -Fq(v)
+            acc += Fq(v) * gi * zh / (Fq(n) * (zeta - gi))
+            gi *= self.g
+        return -acc
 
     def public_input_poly(self, R, x):
         """PI(X) = -sum_i x_i L_i(X) over the first len(x) rows."""
@@ -206,7 +228,7 @@ class Verifier:
         u = tr.get_challenge("u")
         zn = zeta ** n
         L1z = dom.lagrange_1_at(zeta)
-        PIz = dom.public_input_poly(R, x)(zeta)
+        PIz = dom.public_input_at(x, zeta)
         mul, add, neg, G1 = kzg.multiply, kzg.add, kzg.neg, kzg.G1
 
         def lin(terms):

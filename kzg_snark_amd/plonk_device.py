@@ -146,16 +146,25 @@ class DeviceIndexer:
         n = dom.n
         assert len(qM) == n and len(perm) == 3 * n, "pad the circuit to a power of two first"
         ck, rk = kzg.setup(n + 5, tau=tau)                                           # main.py:85
-        sstar = dom.sigma_star(perm)
-        cols = {"qM": qM, "qL": qL, "qR": qR, "qO": qO, "qC": qC,
-                "S_sigma1": sstar[:n], "S_sigma2": sstar[n:2 * n], "S_sigma3": sstar[2 * n:]}
-        coeffs = {k: alg.ntt(alg.upload(v), dom.g, True) for k, v in cols.items()}     # 8 INTTs
-        pack = torch.stack([coeffs[k] for k in cols]).contiguous()
-        xy, inf = alg.ctx.commit_device(ck.srs, pack.data_ptr(), [n] * len(cols), n)  # 8 MSMs
-        comms = dict(zip(cols, kzg._points(xy, inf)))
+        # sigma*: position j of [0, 3n) carries the label of position perm[j], the labels being H, k1 H, k2 H
+        # (plonk/encoder.py:160-194) -- built and permuted on the device (3n field elements never exist as Python ints)
+        ones = alg.const(n, 1)
+        labels = torch.cat([alg.mul_powers(ones, dom.g, 1), alg.mul_powers(ones, dom.g, int(dom.k1)),
+                            alg.mul_powers(ones, dom.g, int(dom.k2))])
+        with torch.cuda.stream(alg.stream):
+            perm_t = torch.as_tensor(np.asarray(perm, dtype=np.int64)).to(alg.dev)
+            assert perm_t.shape[0] == 3 * n
+            sstar = labels.index_select(0, perm_t)
+        sigma_values = {f"S_sigma{b + 1}": sstar[b * n:(b + 1) * n].contiguous() for b in range(3)}
+        cols = {"qM": qM, "qL": qL, "qR": qR, "qO": qO, "qC": qC}
+        on_dev = {k: alg.upload(v) for k, v in cols.items()}
+        on_dev.update({k: v.clone() for k, v in sigma_values.items()})
+        coeffs = {k: alg.ntt(v, dom.g, True) for k, v in on_dev.items()}               # 8 INTTs
+        pack = torch.stack([coeffs[k] for k in coeffs]).contiguous()
+        xy, inf = alg.ctx.commit_device(ck.srs, pack.data_ptr(), [n] * len(coeffs), n)  # 8 MSMs
+        comms = dict(zip(coeffs, kzg._points(xy, inf)))
         sub = {"n": n, "g": dom.g, "k1": dom.k1, "k2": dom.k2}
-        ipk = {"ck": ck, "coeffs": coeffs, "sigma_values": {k: alg.upload(cols[k]) for k in
-                                                            ("S_sigma1", "S_sigma2", "S_sigma3")},
+        ipk = {"ck": ck, "coeffs": coeffs, "sigma_values": sigma_values,
                "subgroups": sub, "commitments": comms}
         ivk = {"rk": rk, "commitments": comms, "subgroups": sub}
         return ipk, ivk

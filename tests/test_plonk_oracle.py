@@ -226,3 +226,24 @@ def test_config5_round_at_2p20_gates():
         want = kzg._g1.normalize(kzg.multiply(kzg.G1, ev(name, tau)))
         pt = proof["commitments"][name]
         assert (int(pt[0]), int(pt[1])) == (int(want[0]), int(want[1])), name
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_verifier_public_input_evaluation_matches_the_interpolated_polynomial(curve):
+    """Domain.public_input_at (what the verifier uses, O(len(x))) against the oracle's PI(X) = -sum x_i L_i(X)
+    (plonk/encoder.py:237-257) evaluated at the same point, off and on the domain."""
+    from kzg_snark_amd.kzg import KZG
+    from kzg_snark_amd.plonk import Domain
+    Fq = KZG(curve).Fq
+    r = int(Fq.order()) if hasattr(Fq, "order") else KZG(curve).curve_order
+    rng = random.Random(5)
+    for n in (4, 16, 64):
+        dom = Domain(Fq, n)
+        assert dom._H is None                                    # nothing of size n is built for the verifier
+        g = int(dom.g)
+        x = [rng.randrange(r) for _ in range(min(5, n))]
+        PI = P.public_input_poly(x, n, g, r)
+        for zeta in (rng.randrange(r), rng.randrange(r), pow(g, 2, r), pow(g, n - 1, r), 1):
+            want = sum(c * pow(zeta, i, r) for i, c in enumerate(PI)) % r
+            assert int(dom.public_input_at(x, zeta)) == want, (curve, n, zeta)
+        assert int(dom.public_input_at([], 12345)) == 0

@@ -24,6 +24,8 @@ The same JSON line also carries
                                          verified against the trapdoor identities (n_gpus = 1: the whole job);
   * distributed_ntt                      (N >= 2) the four-step 2^24 transform over RCCL all-to-all, verified
                                          against the single-GPU transform;
+  * plonk_round                          (N = 1) BASELINE config 5: index -> prove -> verify of a synthetic 2^20-gate
+                                         circuit, prover resident on the GPU; ms per prover round, verifier accepts;
   * cpu_baseline / cpu_baseline_optimised   rank 0 at N = 1: the oracle's C restatement of the reference
                                          algorithms on 1 core, and a multi-threaded Montgomery + Pippenger
                                          CPU implementation on all host cores.
@@ -76,6 +78,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-open", action="store_true", help="skip the KZG.open section")
     ap.add_argument("--no-range", action="store_true", help="skip the range-sharded config-4 section")
     ap.add_argument("--no-dist-ntt", action="store_true", help="skip the distributed NTT section")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the config-5 PLONK round (one GPU only)")
+    ap.add_argument("--plonk-log-n", type=int, default=20, help="gates of the PLONK round (config 5: 2^20)")
     ap.add_argument("--range-log-n", type=int, default=24, help="degree of the range-sharded job (config 4: 24)")
     ap.add_argument("--range-steps", type=int, default=5)
     ap.add_argument("--open-k", type=int, default=6, help="polynomials per opening (plonk/prover.py:184 opens 6)")
@@ -432,6 +436,45 @@ def section_range(env):
     return out, bool(ok_commit and ok_open)
 
 
+def section_plonk(env):
+    """BASELINE config 5: index -> prove -> verify of a synthetic mul/add-chain circuit of 2^20 gates with the
+    prover's polynomials resident on the GPU (kzg_snark_amd/plonk_device.py; plonk/prover.py:24-212).  The value
+    is the wall time of a prover round with the witness handed over as limbs (what a native witness generator
+    emits), median of three after the first; the verifier must accept the last proof."""
+    torch = env.torch
+    from kzg_snark_amd import plonk, plonk_device
+    n = 1 << env.args.plonk_log_n
+    prev = torch.cuda.current_stream(env.dev)
+    t = {}
+    t0 = time.perf_counter()
+    qM, qL, qR, qO, qC, perm, x, w = plonk.synthetic_circuit(n, env.kzg.Fq, seed=env.args.plonk_log_n)
+    t["circuit_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    idx = plonk_device.DeviceIndexer(env.args.curve)
+    ipk, ivk = idx.preprocess(qM, qL, qR, qO, qC, perm)
+    t["index_s"] = time.perf_counter() - t0
+    prv = plonk_device.DeviceProver(env.args.curve, alg=idx.alg)
+    t0 = time.perf_counter()
+    proof = prv.prove(ipk, x, w)
+    t["prove_first_s"] = time.perf_counter() - t0
+    w_limbs = env.native.ints_to_limbs([int(v) for v in w])
+    rounds = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        proof = prv.prove(ipk, x, w_limbs)
+        rounds.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    ok = bool(plonk.Verifier(env.args.curve).verify(ivk, x, proof))
+    t["verify_s"] = time.perf_counter() - t0
+    del ipk, prv, idx
+    torch.cuda.set_stream(prev)
+    torch.cuda.empty_cache()
+    out = {"metric": "PLONK prover round, 2^%d gates, %s, device-resident" % (env.args.plonk_log_n, env.args.curve),
+           "value": sorted(rounds)[1] * 1e3, "unit": "ms", "higher_is_better": False, "gates": n,
+           "rounds_ms": [v * 1e3 for v in rounds], **t, "verified": {"verifier_accepts": ok}}
+    return out, ok
+
+
 def section_dist_ntt(env):
     """The four-step transform of 2^log_n elements sharded over the ranks (sharding.DistributedNTT): forward
     in natural order (three all-to-alls), inverse into the transposed layout (two).  Every rank also runs
@@ -643,6 +686,9 @@ def main(argv=None):
         ok_sections &= ok
     if args.mode == "all" and world > 1 and not args.no_dist_ntt:
         sections["distributed_ntt"], ok = section_dist_ntt(env)
+        ok_sections &= ok
+    if args.mode == "all" and world == 1 and not args.no_plonk:
+        sections["plonk_round"], ok = section_plonk(env)
         ok_sections &= ok
 
     spans = dict(spans_main)

@@ -174,13 +174,14 @@ class DeviceProver:
     def __init__(self, curve_type="bls12_381", alg=None):
         self.kzg = KZG(curve_type)
         self.alg = alg or DeviceAlgebra(curve_type)
+        self._dom_cache = {}                     # (n, g) -> device vectors of that evaluation domain (one entry)
 
     def _domain_constants(self, n, g):
         """Vectors that depend only on the evaluation domain (not on the circuit or the witness), built once per
         domain size and kept on the device: 1, g^i on H; on the coset K*H' of the size-4n subgroup the points x,
         1/Z_H(x) and L1(x) = Z_H(x) / (n (x - 1))."""
         key = (n, int(g))
-        cache = self.__dict__.setdefault("_dom_cache", {})
+        cache = self._dom_cache
         if key not in cache:
             alg, Fq = self.alg, self.kzg.Fq
             r = self.kzg.curve_order

@@ -676,20 +676,29 @@ def main(argv=None):
     ctx.prof_enable(False)
 
     sections, ok_sections = {}, True
-    if args.mode == "all" and not args.no_open:
-        sections["open"], ok = section_open(env, srs, n)
+
+    def run_section(name, fn, *fargs):
+        """The sections ride on the headline line; one that raises is reported as such in its place (and on
+        stderr, and in the exit code) instead of taking the headline measurement down with it."""
+        nonlocal ok_sections
+        try:
+            sections[name], ok = fn(*fargs)
+        except Exception as e:   # noqa: BLE001 -- whatever it is, it is reported, not swallowed
+            import traceback
+            traceback.print_exc()
+            sections[name], ok = {"error": f"{type(e).__name__}: {e}", "verified": False}, False
         ok_sections &= ok
+
+    if args.mode == "all" and not args.no_open:
+        run_section("open", section_open, env, srs, n)
     del srs, works, evals
     torch.cuda.empty_cache()
     if args.mode == "all" and not args.no_range:
-        sections["range_mode"], ok = section_range(env)
-        ok_sections &= ok
+        run_section("range_mode", section_range, env)
     if args.mode == "all" and world > 1 and not args.no_dist_ntt:
-        sections["distributed_ntt"], ok = section_dist_ntt(env)
-        ok_sections &= ok
+        run_section("distributed_ntt", section_dist_ntt, env)
     if args.mode == "all" and world == 1 and not args.no_plonk:
-        sections["plonk_round"], ok = section_plonk(env)
-        ok_sections &= ok
+        run_section("plonk_round", section_plonk, env)
 
     spans = dict(spans_main)
     spans["ntt_pass"] = (ntt_alone[0] * args.steps / ntt_iters, ntt_alone[1] * args.steps // ntt_iters)

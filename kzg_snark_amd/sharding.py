@@ -131,6 +131,31 @@ class DistributedCommitter:
                 ev0 = int.from_bytes(blob[POINT_BYTES + 1:], "little")
         return acc, ev0
 
+    def commit_and_open_range(self, start_commit_fn, collect_commit_fn, begin_fn, finish_fn, z, modulus, n_total):
+        """commit_range and open_range of one step with the two local MSMs sharing the commit pipeline:
+        start_commit_fn() queues this rank's partial commitment (kzg_commit_device_async) and returns at once, the
+        opening's slice evaluation and carry exchange run beside it, finish_fn's MSM follows it through the pipeline,
+        and collect_commit_fn() hands back the partial commitment afterwards (kzg_commit_flush).  Two exchanges per
+        step instead of three: the field elements, then ONE record per rank holding both partial points (+ P(z)).
+        Returns (commitment, (proof, P(z)))."""
+        world, rank = self.world, self.rank
+        start_commit_fn()
+        H = [int.from_bytes(b, "little") for b in self._gather(int(begin_fn()).to_bytes(FR_BYTES, "little"))]
+        lo_hi = [range_of(g, world, n_total) for g in range(world)]
+        hi = lo_hi[rank][1]
+        carry = sum(H[g] * pow(z, lo_hi[g][0] - hi, modulus) for g in range(rank + 1, world)) % modulus
+        part_open, ev = finish_fn(carry, rank == 0)
+        part_commit = collect_commit_fn()
+        payload = pack_point(part_commit) + pack_point(part_open) + (
+            b"\x00" * (FR_BYTES + 1) if ev is None else b"\x01" + int(ev).to_bytes(FR_BYTES, "little"))
+        com, prf, ev0 = self.zero, self.zero, None
+        for g, blob in enumerate(self._gather(payload)):
+            com = self.add_fn(com, unpack_point(blob[:POINT_BYTES]))
+            prf = self.add_fn(prf, unpack_point(blob[POINT_BYTES:2 * POINT_BYTES]))
+            if g == 0 and blob[2 * POINT_BYTES] == 1:
+                ev0 = int.from_bytes(blob[2 * POINT_BYTES + 1:], "little")
+        return com, (prf, ev0)
+
     def commit_range(self, local_coeffs):
         """local_coeffs: this rank's contiguous slice of ONE polynomial (its SRS shard is what
         commit_fn commits against).  Returns the commitment to the whole polynomial on every rank."""

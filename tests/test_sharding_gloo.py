@@ -81,6 +81,13 @@ def _worker(rank, world, port, q):
         proof, ev = dc2.open_range(begin, finish, z, r, n)
         want, pz = O.open_(full_ck, polys3, z, xi, cv)
         assert proof == to_pt(want) and ev == pz, "range-mode open"
+
+        # the fused step (one polynomial committed and k opened, two exchanges): same results
+        box = {}
+        com, (proof2, ev2) = dc2.commit_and_open_range(
+            lambda: box.setdefault("c", to_pt(O.commit(shard_ck, [p[lo:hi]], cv)[0])), lambda: box["c"],
+            begin, finish, z, r, n)
+        assert com == to_pt(O.commit(full_ck, [p], cv)[0]) and proof2 == proof and ev2 == ev, "fused range step"
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))

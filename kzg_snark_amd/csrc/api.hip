@@ -317,8 +317,19 @@ int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const 
   const size_t bytes = n_polys * stride * 32;
   int rc = ensure_buf(c, c->io, bytes ? bytes : 32);
   if (rc) return rc;
-  if (bytes) KZG_HIP(c, hipMemcpyAsync(c->io.p, scalars, bytes, hipMemcpyHostToDevice, c->stream));
-  return commit_device(c, srs->s, static_cast<const uint32_t*>(c->io.p), lens, n_polys, stride, out_xy, out_inf);
+  // One polynomial at a time: the copy of polynomial p + 1 is ordered on the context's stream behind the prep of
+  // polynomial p (which is all that reads p's scalars) and so travels while p is being accumulated.
+  const size_t fpw = (c->curve == 0 ? Bn254::Fp::NW : Bls12_381::Fp::NW) / 2;   // 64-bit words per coordinate
+  auto* io = static_cast<uint32_t*>(c->io.p);
+  for (size_t p = 0; p < n_polys; ++p) {
+    if (lens[p] > stride) return set_err(c, KZG_ERR_ARG, "kzg_commit: lens[p] > stride");
+    if (lens[p] && lens[p] <= srs->s->n)
+      KZG_HIP(c, hipMemcpyAsync(io + p * stride * 8, scalars + p * stride * 4, lens[p] * 32, hipMemcpyHostToDevice,
+                                c->stream));
+    rc = commit_device(c, srs->s, io + p * stride * 8, lens + p, 1, stride, out_xy + p * 2 * fpw, out_inf + p, false);
+    if (rc) { commit_flush(c); return rc; }
+  }
+  return commit_flush(c);
 }
 
 int kzg_open_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys, const size_t* lens, size_t k,

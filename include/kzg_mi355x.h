@@ -144,8 +144,9 @@ void kzg_srs_free(kzg_srs* srs);
  * n_polys coefficient arrays, `stride` elements apart, polynomial p having lens[p] coefficients
  * (low to high).  One affine point per polynomial: out_xy[p] (2*FP_LIMBS limbs), out_inf[p] = 1
  * for the point at infinity (zero polynomial, kzg.py:109).  lens[p] > kzg_srs_size(srs) returns
- * KZG_ERR_DEGREE -- the ValueError of kzg.py:103-106.  Zero coefficients contribute nothing
- * (kzg.py:113-114). */
+ * KZG_ERR_DEGREE -- the ValueError of kzg.py:103-106 -- before any work is queued.  Zero coefficients
+ * contribute nothing (kzg.py:113-114).  The scalars are in host memory: polynomial p + 1 is copied to
+ * the device while polynomial p is being accumulated. */
 int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const size_t* lens, size_t n_polys,
                size_t stride, uint64_t* out_xy, uint8_t* out_inf);
 /* Same with device-resident scalars; results are still written to host memory (one point per

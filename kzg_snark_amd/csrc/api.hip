@@ -321,9 +321,12 @@ int kzg_commit(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t* scalars, const 
   // polynomial p (which is all that reads p's scalars) and so travels while p is being accumulated.
   const size_t fpw = (c->curve == 0 ? Bn254::Fp::NW : Bls12_381::Fp::NW) / 2;   // 64-bit words per coordinate
   auto* io = static_cast<uint32_t*>(c->io.p);
-  for (size_t p = 0; p < n_polys; ++p) {
+  for (size_t p = 0; p < n_polys; ++p) {   // all arguments are checked before any work is queued
+    if (lens[p] > srs->s->n) return set_err(c, KZG_ERR_DEGREE, "polynomial longer than the commitment key");
     if (lens[p] > stride) return set_err(c, KZG_ERR_ARG, "kzg_commit: lens[p] > stride");
-    if (lens[p] && lens[p] <= srs->s->n)
+  }
+  for (size_t p = 0; p < n_polys; ++p) {
+    if (lens[p])
       KZG_HIP(c, hipMemcpyAsync(io + p * stride * 8, scalars + p * stride * 4, lens[p] * 32, hipMemcpyHostToDevice,
                                 c->stream));
     rc = commit_device(c, srs->s, io + p * stride * 8, lens + p, 1, stride, out_xy + p * 2 * fpw, out_inf + p, false);

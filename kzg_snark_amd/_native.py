@@ -396,9 +396,34 @@ def get_context(curve_type, device=0):
 
 # ---- integer <-> limb marshalling -------------------------------------------------
 
+def _load_pyconv():
+    """csrc/pyconv.c built by kzg_snark_amd.build (CPython API; marshalling only).  Absent: the Python forms below."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_kzg_pyconv.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        import importlib.machinery
+        import importlib.util
+        loader = importlib.machinery.ExtensionFileLoader("_kzg_pyconv", path)
+        spec = importlib.util.spec_from_loader("_kzg_pyconv", loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        return mod
+    except Exception:   # noqa: BLE001 -- built for another interpreter, say: the Python forms still work
+        return None
+
+
+_pyconv = _load_pyconv()
+
+
 def ints_to_limbs(values, limbs=4):
     """list of non-negative ints (< 2^(64*limbs)) -> uint64[n, limbs] (little-endian)."""
     nb = 8 * limbs
+    if _pyconv is not None:
+        if not isinstance(values, (list, tuple)):
+            values = list(values)
+        buf = _pyconv.ints_to_bytes(values, nb)          # a bytearray: wrapped, not copied
+        return np.frombuffer(buf, dtype="<u8").reshape(len(values), limbs)
     try:                                   # plain ints (what every facade path passes): 1.8x the generator form
         buf = b"".join(map(_methodcaller("to_bytes", nb, "little"), values))
     except AttributeError:                 # field elements and other int()-able objects
@@ -409,6 +434,8 @@ def ints_to_limbs(values, limbs=4):
 def limbs_to_ints(arr):
     a = np.ascontiguousarray(arr, dtype="<u8")
     nb = 8 * a.shape[-1]
+    if _pyconv is not None:
+        return _pyconv.bytes_to_ints(a.reshape(-1).view(np.uint8), nb)
     raw = a.tobytes()
     return [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
 

@@ -37,8 +37,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+PYCONV = os.path.join(LIBDIR, "_kzg_pyconv.so")
+
+
+def build_pyconv(force=False, verbose=True):
+    """The CPython helper for int <-> limb marshalling (csrc/pyconv.c, plain C, no GPU code)."""
+    import sysconfig
+    src = os.path.join(CSRC, "pyconv.c")
+    if not (force or _stale(PYCONV, [src])):
+        return PYCONV
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], src,
+           "-o", PYCONV]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return PYCONV
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
+    build_pyconv(force, verbose)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = _deps()
     objs = []

@@ -169,3 +169,39 @@ def test_transcript_bytes():
     assert t.state == hashlib.sha256(s1 + b"beta" + h).digest()
     with pytest.raises(struct.error):
         t.append_message("big", 1 << 70)          # the reference's ">q" packing has the same limit
+
+
+def test_int_marshalling_helper_matches_the_python_forms():
+    """csrc/pyconv.c (CPython-API int <-> limb conversion used by every list-taking facade call) against
+    int.to_bytes / int.from_bytes, including the error cases int.to_bytes raises."""
+    import random
+    import numpy as np
+    from kzg_snark_amd import _native, build
+    from kzg_snark_amd.field import GF
+    build.build_pyconv(verbose=False)
+    pc = _native._load_pyconv()
+    assert pc is not None, "the helper builds with the image's gcc + Python.h"
+    rng = random.Random(11)
+    for nb in (32, 48):
+        vals = [0, 1, (1 << (8 * nb)) - 1, 1 << 63, (1 << 64) - 1, 1 << 64] + [rng.getrandbits(8 * nb) for _ in range(200)]
+        raw = bytes(pc.ints_to_bytes(vals, nb))
+        assert raw == b"".join(v.to_bytes(nb, "little") for v in vals)
+        assert pc.bytes_to_ints(raw, nb) == vals
+        assert pc.bytes_to_ints(np.frombuffer(raw, dtype=np.uint8), nb) == vals
+    assert bytes(pc.ints_to_bytes([], 32)) == b"" and pc.bytes_to_ints(b"", 32) == []
+    assert bytes(pc.ints_to_bytes((5, 6), 32)) == (5).to_bytes(32, "little") + (6).to_bytes(32, "little")
+    F = GF(_native.R_BLS if hasattr(_native, "R_BLS") else 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001)
+    assert pc.bytes_to_ints(bytes(pc.ints_to_bytes([F(7), F(-1)], 32)), 32) == [7, int(F(-1))]    # int()-able elements
+    for bad in ([-1], [1 << 256]):
+        with pytest.raises(OverflowError):
+            pc.ints_to_bytes(bad, 32)
+    with pytest.raises(TypeError):
+        pc.ints_to_bytes([1.5j], 32)
+    with pytest.raises(ValueError):
+        pc.bytes_to_ints(b"123", 32)
+    # and through the module-level functions the facade calls
+    vals = [rng.getrandbits(255) for _ in range(1000)]
+    limbs = _native.ints_to_limbs(vals)
+    assert limbs.shape == (1000, 4) and limbs.dtype == np.uint64 and limbs.flags.writeable
+    assert _native.limbs_to_ints(limbs) == vals
+    assert _native.limbs_to_ints(limbs[::2]) == vals[::2]                                          # non-contiguous input

@@ -51,7 +51,11 @@ def _transform(seq, w, F, inverse):
         ctx.fft_ff_any(data, ww, inverse)
     else:
         ctx.ntt(data, n.bit_length() - 1, ww, inverse)
-    return data if as_buffer else [F(v) for v in _native.limbs_to_ints(data)]
+    if as_buffer:
+        return data
+    out = _native.limbs_to_ints(data)                       # canonical: the kernels reduce below r
+    bulk = getattr(F, "elements", None)                     # our PrimeField; a Sage GF is called per element
+    return bulk(out) if bulk is not None else [F(v) for v in out]
 
 
 def fft_ff(coeffs, w, F):

@@ -83,6 +83,12 @@ class PrimeField:
             return x if x.F.p == self.p else FieldElement(x.v % self.p, self)
         return FieldElement(int(x) % self.p, self)
 
+    def elements(self, canonical):
+        """Field elements for a list of ints already in [0, p) (what the engine returns): the bulk form of
+        [F(v) for v in canonical] without the per-element coercion."""
+        from itertools import repeat
+        return list(map(FieldElement, canonical, repeat(self)))
+
     def order(self): return self.p
     def characteristic(self): return self.p
     cardinality = order

@@ -163,6 +163,13 @@ class KZG:
         r = self.curve_order
         if isinstance(poly, Polynomial):
             return poly.c
+        if isinstance(poly, np.ndarray) and poly.dtype == np.uint64 and poly.ndim == 2 and poly.shape[1] == 4:
+            # buffer fast path (as in fft_ff): canonical little-endian limbs, no per-element Python objects;
+            # trailing zero coefficients dropped like everywhere else
+            if poly.shape[0] and poly[-1].any():                  # the usual case: nothing to trim, nothing to scan
+                return np.ascontiguousarray(poly)
+            nz = np.flatnonzero(poly.any(axis=1))
+            return np.ascontiguousarray(poly[:int(nz[-1]) + 1 if nz.size else 0])
         if isinstance(poly, (list, tuple)):
             c = [int(x) % r for x in poly]
         else:
@@ -174,10 +181,12 @@ class KZG:
     def _pack(self, coeff_lists):
         stride = max((len(c) for c in coeff_lists), default=0)
         stride = max(stride, 1)
+        if len(coeff_lists) == 1 and isinstance(coeff_lists[0], np.ndarray) and len(coeff_lists[0]):
+            return coeff_lists[0].reshape(1, stride, 4), [stride], stride          # one buffer: handed over as it is
         arr = np.zeros((len(coeff_lists), stride, 4), dtype=np.uint64)
         for i, c in enumerate(coeff_lists):
-            if c:
-                arr[i, :len(c)] = _native.ints_to_limbs(c)
+            if len(c):
+                arr[i, :len(c)] = c if isinstance(c, np.ndarray) else _native.ints_to_limbs(c)
         return arr, [len(c) for c in coeff_lists], stride
 
     def _points(self, xy, inf):

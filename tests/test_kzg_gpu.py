@@ -518,3 +518,25 @@ def test_pipelined_open_matches_the_synchronous_one(native, curve):
         else:
             assert tuple(native.limbs_to_ints(cxy[0].reshape(2, L))) == O.normalize(O.multiply(G1, cwant, cv), cv)
     ctx.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_limb_buffers_are_accepted_like_lists(native, kzgs, small_keys, curve):
+    """KZG.commit / KZG.open with uint64[n, 4] limb buffers (the fast path that skips Python-int marshalling,
+    as fft_ff has it): same points as with the lists, trailing zero coefficients and the degree check included."""
+    import numpy as np
+    cv = O.curve(curve)
+    kzg = kzgs[curve]
+    ck, _ = small_keys[curve]
+    rng = random.Random(77)
+    polys = [[rng.randrange(cv.r) for _ in range(n)] for n in (64, 17, 1)] + [[3, 0, 5, 0, 0], [0, 0], []]
+    bufs = [native.ints_to_limbs(p).reshape(-1, 4) if p else np.zeros((0, 4), dtype=np.uint64) for p in polys]
+    assert kzg.commit(ck, bufs) == kzg.commit(ck, polys)
+    assert kzg.commit(ck, [bufs[0], polys[1]]) == kzg.commit(ck, polys[:2])                      # mixed forms in one call
+    z, xi = rng.randrange(cv.r), rng.randrange(cv.r)
+    assert kzg.open(ck, bufs[:3], z, xi) == kzg.open(ck, polys[:3], z, xi)
+    too_long = native.ints_to_limbs([1] * 65)
+    with pytest.raises(ValueError):
+        kzg.commit(ck, [too_long])
+    padded = np.concatenate([bufs[0], np.zeros((9, 4), dtype=np.uint64)])                         # degree 63 with zero padding
+    assert kzg.commit(ck, [padded]) == kzg.commit(ck, [polys[0]])

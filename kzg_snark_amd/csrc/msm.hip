@@ -717,6 +717,7 @@ constexpr int NSLOT = 4;
 
 struct MsmSlot {
   DevBuf prep_ws, vals, bstart, order, slice_off, counter, chunk_rank;              // prep
+  DevBuf scal;                 // the polynomial's scalars, copied at enqueue (KZG_COMMIT_COPY_SCALARS)
   DevBuf partials, buckets, rowsum, colsum, rowpart, colpart, tb;
   void* h_tb = nullptr;        // pinned host copy of the partial points (+ 32 bytes behind them: P(z) of a pipelined open)
   uint64_t* out_eval = nullptr;   // where that P(z) goes when the slot is retired
@@ -745,7 +746,7 @@ void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;
   for (auto& sl : w->slot) {
-    for (DevBuf* b : {&sl.prep_ws, &sl.vals, &sl.bstart, &sl.order, &sl.slice_off, &sl.counter, &sl.chunk_rank, &sl.partials,
+    for (DevBuf* b : {&sl.scal, &sl.prep_ws, &sl.vals, &sl.bstart, &sl.order, &sl.slice_off, &sl.counter, &sl.chunk_rank, &sl.partials,
                       &sl.buckets, &sl.rowsum, &sl.colsum, &sl.rowpart, &sl.colpart, &sl.tb})
       hipFree(b->p);
     if (sl.h_tb) hipHostFree(sl.h_tb);
@@ -805,6 +806,15 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
   hipStream_t sp = w->stream_p, sa = w->stream_a, sb = w->stream_b;
 
   // ---- stage P: prep
+  // The scalars are first copied into the slot (n x 32 bytes on the context's stream, ~25 us at 2^20): the caller's
+  // buffer is free as soon as that copy has run, so what it enqueues next on the context's stream -- the next
+  // transform, the next opening's polynomial stage -- does not queue behind this polynomial's prep (~0.5 ms).
+  static const bool copy_scalars = [] { const char* e = getenv("KZG_COMMIT_COPY_SCALARS"); return !(e && atoi(e) == 0); }();
+  if (copy_scalars) {
+    if ((rc = ensure_buf(c, sl.scal, (size_t)n * 32))) return rc;
+    KZG_HIP(c, hipMemcpyAsync(sl.scal.p, d_scalars, (size_t)n * 32, hipMemcpyDeviceToDevice, c->stream));
+    d_scalars = static_cast<const uint32_t*>(sl.scal.p);
+  }
   KZG_HIP(c, hipEventRecord(sl.ev_in, c->stream));
   KZG_HIP(c, hipStreamWaitEvent(sp, sl.ev_in, 0));
 #ifdef KZG_TIMING_SKIP_PREP   // timing experiment only (results are wrong): reuse the slot's previous prep output
@@ -816,7 +826,7 @@ static int msm_enqueue(Ctx* c, const Srs* s, const uint32_t* d_scalars, uint32_t
                              static_cast<uint32_t*>(sl.chunk_rank.p), nchunk_max)))
     return rc;
   KZG_HIP(c, hipEventRecord(sl.ev_p, sp));
-  KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
+  if (!copy_scalars) KZG_HIP(c, hipStreamWaitEvent(c->stream, sl.ev_p, 0));   // the scalars are free again from here on
 
   // ---- stage A: accumulate
   KZG_HIP(c, hipStreamWaitEvent(sa, sl.ev_p, 0));

@@ -155,9 +155,11 @@ int kzg_commit_device(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, c
                       size_t stride, uint64_t* out_xy, uint8_t* out_inf);
 
 /* Pipelined form: returns after enqueueing; up to four polynomials stay in flight across calls.
- * The scalars of an in-flight polynomial must stay untouched and out_xy / out_inf stay valid
- * until kzg_commit_flush() returns (or until a later call on this context has recycled the
- * slot); results are written by the host thread inside those calls. */
+ * The scalars are copied at enqueue, in the order of the context's stream: work queued on that
+ * stream afterwards (the next transform into the same buffer, say) may overwrite them, anything
+ * else must wait for the stream.  out_xy / out_inf stay valid until kzg_commit_flush() returns
+ * (or until a later call on this context has recycled the slot); results are written by the host
+ * thread inside those calls. */
 int kzg_commit_device_async(kzg_ctx* ctx, const kzg_srs* srs, const void* d_scalars, const size_t* lens,
                             size_t n_polys, size_t stride, uint64_t* out_xy, uint8_t* out_inf);
 int kzg_commit_flush(kzg_ctx* ctx);

@@ -59,11 +59,12 @@ def unpack_point(rec):
     return (int.from_bytes(rec[:COORD_BYTES], "little"), int.from_bytes(rec[COORD_BYTES:2 * COORD_BYTES], "little"), 1)
 
 
-def all_gather_bytes(payload, group=None):
+def all_gather_bytes(payload, group=None, always=False):
     """Every rank contributes `payload` (same length everywhere); returns the list of all ranks'
     payloads in rank order.  One all_gather of a uint8 tensor: on the current CUDA device under
-    RCCL ("nccl"), on the host under gloo."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    RCCL ("nccl"), on the host under gloo.  `always`: issue the collective even in a one-rank group
+    (tests: the RCCL call path on a single GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
         return [bytes(payload)]
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
@@ -194,6 +195,7 @@ class DistributedNTT:
         self.ops = ops
         self.group = group
         self._exchange = exchange
+        self.always_exchange = False     # tests: issue the all-to-all even in a one-rank group (RCCL call path on one GPU)
 
     @property
     def world(self):
@@ -209,7 +211,7 @@ class DistributedNTT:
         assert send.is_contiguous()
         if self._exchange is not None:
             return self._exchange(send)
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return send
         if send.is_cuda and dist.get_backend(self.group) != "nccl":
             # rehearsal on one GPU: gloo moves host memory only

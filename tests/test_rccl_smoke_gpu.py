@@ -1,0 +1,80 @@
+"""The collectives bench.py and kzg_snark_amd/sharding.py issue under the "nccl" (RCCL) backend, exercised on the one
+GPU a test box has: a one-rank RCCL process group accepts the same calls with the same dtypes (uint8 records, int64
+limb blocks, float64 / int64 reductions).  This cannot show scaling -- it shows that the calls the N-GPU run makes are
+ones this RCCL build takes.  The exchange logic itself is covered with two gloo ranks in tests/test_sharding_gloo.py."""
+import os
+import socket
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_one_rank_rccl_group_takes_the_calls_the_multi_gpu_paths_make():
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        # bench.py Env.max_over_ranks / the verification flag
+        t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.25
+        f = torch.tensor([1], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        assert int(f.item()) == 1
+        # sharding.all_gather_bytes: fixed-size uint8 records
+        rec = torch.frombuffer(bytearray(range(97)), dtype=torch.uint8).to(dev)
+        outs = [torch.empty_like(rec)]
+        dist.all_gather(outs, rec)
+        assert bytes(outs[0].cpu().numpy().tobytes()) == bytes(range(97))
+        # sharding.DistributedNTT.exchange: blocks of 32-byte field elements as int64[.., 4]
+        send = torch.arange(4 * 1024, dtype=torch.int64, device=dev).view(1024, 4).contiguous()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)
+        assert torch.equal(recv, send)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+        # the same through the product's own helpers, forced to issue their collective in this one-rank group:
+        # a G1 record, and a whole 2^14 transform through DistributedNTT on the device (both layouts)
+        import numpy as np
+        from kzg_snark_amd import _native
+        from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps, all_gather_bytes, pack_point, unpack_point
+        pt = (12345, 67890, 1)
+        assert [unpack_point(b) for b in all_gather_bytes(pack_point(pt), always=True)] == [pt]
+        ctx = _native.get_context("bls12_381")
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            ctx.bind_torch_stream(stream)
+            log_n, r = 14, 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+            w = pow(7, (r - 1) >> log_n, r)
+            ww = _native.int_to_words(w)
+            rs = np.random.RandomState(4)
+            host = rs.randint(0, 1 << 62, size=(1 << log_n, 4)).astype(np.uint64)
+            host[:, 3] >>= np.uint64(3)
+            want = host.copy()
+            ctx.ntt(want, log_n, ww, False)                                   # single-GPU transform, host entry
+            x = torch.from_numpy(host.view(np.int64)).to(dev)
+            d = DistributedNTT(GpuNttOps(ctx, log_n, ww, False))
+            d.always_exchange = True
+            got = d.transform(x, log_n, layout="natural")
+            ctx.synchronize()
+            assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+        ctx.bind_torch_stream(torch.cuda.default_stream(dev))
+    finally:
+        dist.destroy_process_group()

@@ -86,6 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: rehearsal of the "
                                                       "multi-rank path with all ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="one GPU: bring up a ONE-rank process group and issue every collective the N-GPU run issues "
+                         "(RCCL call path, dtypes, stream ordering); times nothing worth quoting")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher self-test without a GPU: the ranks rendezvous over gloo, all-gather one record "
                          "each and rank 0 prints one JSON line")
@@ -261,18 +264,19 @@ class Env:
     def __init__(self, args, torch, dist, ctx, dev, world, rank, native):
         self.args, self.torch, self.dist, self.ctx, self.dev = args, torch, dist, ctx, dev
         self.world, self.rank, self.native = world, rank, native
+        self.collective = world > 1 or (dist is not None and dist.is_initialized())   # one-rank rehearsal included
         from kzg_snark_amd.kzg import KZG
         self.kzg = KZG(args.curve)
         self.r = self.kzg.curve_order
 
     def barrier(self):
         self.torch.cuda.synchronize(self.dev)
-        if self.world > 1:
+        if self.collective:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, seconds):
-        if self.world == 1:
+        if not self.collective:
             return seconds
         t = self.torch.tensor([seconds], device=self.dev if self.args.backend == "nccl" else "cpu",
                               dtype=self.torch.float64)
@@ -527,7 +531,7 @@ def section_dist_ntt(env):
             assert int(gidx[1]) == transposed_index(log_n, world, rank, 1)
             ok = bool(torch.equal(res, ref[gidx]))
         flag = torch.tensor([1 if ok else 0], device=env.dev if args.backend == "nccl" else "cpu")
-        if world > 1:
+        if env.collective:
             env.dist.all_reduce(flag, op=env.dist.ReduceOp.MIN)
         ok = bool(int(flag.item()))
         ok_all &= ok
@@ -568,9 +572,19 @@ def main(argv=None):
                          f"{torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    rehearse = args.rehearse_collectives and world == 1
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if rehearse:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            from kzg_snark_amd import sharding
+            sharding.FORCE_COLLECTIVES = True
+        # RCCL: name the device of this rank (set above) instead of letting the backend guess it from the global rank
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                **({"device_id": dev} if args.backend == "nccl" else {}))
 
     from kzg_snark_amd import _native
     ctx = _native.Context(args.curve, device=local_rank)
@@ -582,7 +596,7 @@ def main(argv=None):
     env = Env(args, torch, dist, ctx, dev, world, rank, _native)
 
     def finish(code):
-        if world > 1:
+        if env.collective:
             dist.barrier()
             dist.destroy_process_group()
         return code
@@ -656,7 +670,7 @@ def main(argv=None):
             p_tau = ctx.poly_eval(n, works[last & 1][p].data_ptr(), tau)
             ok_headline &= (not inf_last[p]) and env.affine(env.point(xy_last[p])) == env.g1_times(p_tau)
     flag = torch.tensor([1 if ok_headline else 0], device=dev if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if env.collective:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     ok_headline = bool(int(flag.item()))
 
@@ -705,7 +719,7 @@ def main(argv=None):
     torch.cuda.empty_cache()
     if args.mode == "all" and not args.no_range:
         run_section("range_mode", section_range, env)
-    if args.mode == "all" and world > 1 and not args.no_dist_ntt:
+    if args.mode == "all" and env.collective and not args.no_dist_ntt:
         run_section("distributed_ntt", section_dist_ntt, env)
     if args.mode == "all" and world == 1 and not args.no_plonk:
         run_section("plonk_round", section_plonk, env)

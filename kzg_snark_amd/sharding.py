@@ -59,12 +59,16 @@ def unpack_point(rec):
     return (int.from_bytes(rec[:COORD_BYTES], "little"), int.from_bytes(rec[COORD_BYTES:2 * COORD_BYTES], "little"), 1)
 
 
+# bench.py --rehearse-collectives: issue every collective even in a one-rank group (the RCCL call path on one GPU)
+FORCE_COLLECTIVES = False
+
+
 def all_gather_bytes(payload, group=None, always=False):
     """Every rank contributes `payload` (same length everywhere); returns the list of all ranks'
     payloads in rank order.  One all_gather of a uint8 tensor: on the current CUDA device under
     RCCL ("nccl"), on the host under gloo.  `always`: issue the collective even in a one-rank group
     (tests: the RCCL call path on a single GPU)."""
-    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not (always or FORCE_COLLECTIVES)):
         return [bytes(payload)]
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
@@ -211,7 +215,7 @@ class DistributedNTT:
         assert send.is_contiguous()
         if self._exchange is not None:
             return self._exchange(send)
-        if self.world == 1 and not self.always_exchange:
+        if self.world == 1 and not (self.always_exchange or FORCE_COLLECTIVES):
             return send
         if send.is_cuda and dist.get_backend(self.group) != "nccl":
             # rehearsal on one GPU: gloo moves host memory only

@@ -106,6 +106,12 @@ template <class F>
 __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   using Fd = Field<F>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+#ifndef KZG_NTT_PRIO
+#define KZG_NTT_PRIO 3
+#endif
+  // like prep and the reduce stage: a short kernel that wins instruction issue beside the long accumulate kernel
+  // (alone it changes nothing; in the commit pipeline at B = 4: 416-417 vs 409-410 commits/s on one box, r02c)
+  __builtin_amdgcn_s_setprio(KZG_NTT_PRIO);
   const uint32_t T = blockDim.x, tid = threadIdx.x;
   const uint32_t k = a.k, logC = a.logC;
   const uint32_t LEN = 1u << k, C = 1u << logC, TILE = LEN << logC;

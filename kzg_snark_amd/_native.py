@@ -131,6 +131,16 @@ def lib():
     return _lib
 
 
+def _check_out(a, dtype, size, what):
+    """An output of a pipelined call is written later through a raw pointer: it must be a writable, contiguous numpy
+    array of the right size (a temporary or a list would be gone, or never seen, by then)."""
+    if a is None and what == "eval_out":
+        return
+    if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.flags.writeable
+            and a.size >= size):
+        raise TypeError(f"{what}: need a writable C-contiguous numpy {np.dtype(dtype).name} array of >= {size} elements")
+
+
 def _as_vp(a):
     """numpy array / int device pointer / ctypes array -> c_void_p."""
     if a is None:
@@ -160,11 +170,16 @@ class Context:
         if rc != 0:
             raise NativeError(rc, "kzg_ctx_create failed")
         self._h = h
+        # host arrays (and keys) the library still holds raw pointers to: the outputs of the pipelined entry points
+        # are written when their slot is retired -- by a later commit or by commit_flush() -- so the context keeps
+        # them alive until the flush, whatever the caller does with its own references
+        self._inflight = []
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().kzg_ctx_destroy(self._h)
+            lib().kzg_ctx_destroy(self._h)       # waits for the device; pending results are dropped, not written
             self._h = None
+            self._inflight = []
 
     def __del__(self):
         try:
@@ -286,11 +301,19 @@ class Context:
         """Pipelined commit: results land in the caller's out_xy / out_inf (numpy, kept alive by the
         caller) by the time commit_flush() returns."""
         lens_a = np.asarray(lens, dtype=np.uint64)
+        _check_out(out_xy, np.uint64, len(lens) * 2 * self.fp_limbs, "out_xy")
+        _check_out(out_inf, np.uint8, len(lens), "out_inf")
+        self._inflight.append((srs, out_xy, out_inf))
         self._check(lib().kzg_commit_device_async(self._h, srs._h, _as_vp(d_scalars), _as_vp(lens_a), len(lens),
                                                   stride, _as_vp(out_xy), _as_vp(out_inf)))
 
     def commit_flush(self):
-        self._check(lib().kzg_commit_flush(self._h))
+        """Drain the pipeline: every pending result is on the host when this returns (or raises)."""
+        try:
+            self._check(lib().kzg_commit_flush(self._h))
+        finally:
+            # the library retires every slot in kzg_commit_flush, also on error: nothing points at these any more
+            self._inflight.clear()
 
     def open(self, srs, polys, lens, stride, z_words, xi_words, device=False):
         k = len(lens)
@@ -308,6 +331,10 @@ class Context:
         """Pipelined open: out_xy (uint64[2*fp_limbs]), out_inf (uint8[1]) and eval_out (uint64[4]) -- numpy arrays
         the caller keeps alive -- are filled by the time commit_flush() returns."""
         lens_a = np.asarray(lens, dtype=np.uint64)
+        _check_out(out_xy, np.uint64, 2 * self.fp_limbs, "out_xy")
+        _check_out(out_inf, np.uint8, 1, "out_inf")
+        _check_out(eval_out, np.uint64, 4, "eval_out")
+        self._inflight.append((srs, out_xy, out_inf, eval_out))
         self._check(lib().kzg_open_device_async(self._h, srs._h, _as_vp(d_polys), _as_vp(lens_a), len(lens), stride,
                                                 _as_vp(z_words), _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf),
                                                 _as_vp(eval_out)))

@@ -125,6 +125,15 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
   Ctx* c = &ctx->c;
   KZG_HIP(c, hipSetDevice(c->device));
   if (hip_stream) {
+    // Adopt only what the runtime knows as a stream of this process: any other value would reach hipEventRecord /
+    // hipStreamWaitEvent unchecked later (a host crash, gpurun_out/r02_crash.log).  hipStreamQuery looks the handle up
+    // in the runtime's stream set and resolves the hipStreamLegacy / hipStreamPerThread aliases; "not ready" is a
+    // valid stream with work in flight.
+    const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(hip_stream));
+    if (q != hipSuccess && q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: not a HIP stream of this process", q);
+    }
     if (c->own_stream && c->stream) {
       KZG_HIP(c, hipStreamSynchronize(c->stream));
       KZG_HIP(c, hipStreamDestroy(c->stream));

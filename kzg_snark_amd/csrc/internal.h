@@ -56,7 +56,7 @@ struct Ctx {
   std::string err;
   std::vector<NttDomain> domains;
   uint64_t tick = 0;
-  bool ntt_lds_attr_set = false;   // hipFuncAttributeMaxDynamicSharedMemorySize applies per device
+  uint32_t ntt_lds_attr_set = 0;   // per ntt_pass_kernel instantiation: hipFuncAttributeMaxDynamicSharedMemorySize applies per device
   DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
   DevBuf io;              // staging for the host-pointer entry points
   DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries

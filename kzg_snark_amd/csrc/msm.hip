@@ -909,7 +909,7 @@ static void msm_finish_host(const void* h_tb, uint64_t* out_xy, uint8_t* out_inf
 
 template <class C>
 static int msm_retire(Ctx* c, MsmSlot& sl) {
-  if (!sl.pending) return KZG_OK;
+  if (!sl.pending) { sl.out_eval = nullptr; return KZG_OK; }
   KZG_HIP(c, hipEventSynchronize(sl.ev_b));
   if (sl.win_bits == 20) msm_finish_host<C, 20>(sl.h_tb, sl.out_xy, sl.out_inf);
   else msm_finish_host<C, 16>(sl.h_tb, sl.out_xy, sl.out_inf);
@@ -960,19 +960,21 @@ static int commit_t(Ctx* c, const Srs* s, const uint32_t* d_scalars, const size_
     MsmSlot& sl = w->slot[si];
     w->next = (w->next + 1) % NSLOT;
     if ((rc = msm_retire<C>(c, sl))) break;       // recycle: its stage B has long finished
+    uint64_t* slot_eval = nullptr;
     if (d_eval && out_eval) {
       // P(z) rides with the slot: the copy is ordered on the context's stream BEFORE ev_in, which every stage of
       // this polynomial waits for, so it has landed when the slot's last event (ev_b) has
       if (!sl.h_tb) KZG_HIP(c, hipHostMalloc(&sl.h_tb, MAX_NPART * 4 * 16 * 4 + 32));
       KZG_HIP(c, hipMemcpyAsync(static_cast<char*>(sl.h_tb) + MAX_NPART * 4 * 16 * 4, d_eval, 32,
                                 hipMemcpyDeviceToHost, c->stream));
-      sl.out_eval = out_eval;
+      slot_eval = out_eval;
     }
     const uint32_t* sc = d_scalars + p * stride * 8;
     rc = s->win_bits == 20 ? msm_enqueue<C, 20>(c, s, sc, (uint32_t)lens[p], w, si)
                            : msm_enqueue<C, 16>(c, s, sc, (uint32_t)lens[p], w, si);
-    if (rc) break;
+    if (rc) break;                                 // nothing of this polynomial stays behind in the slot
     sl.pending = true;
+    sl.out_eval = slot_eval;                       // host pointers are adopted only once the work is queued
     sl.out_xy = o;
     sl.out_inf = out_inf + p;
   }

@@ -102,7 +102,64 @@ __device__ __forceinline__ Fe<F> glb_get_limbs(const uint32_t* p) {
   return r;
 }
 
+// How a pass ends (compile-time, one instantiation each: no epilogue branches, no dead registers):
+enum : int {
+  EPI_REDUCE = 0,   // last pass of a forward / two-pass inverse transform: canonical value of the lazy sum
+  EPI_FACTOR = 1,   // pass 1: twist w^(pos*col) = twA[e >> h] * twB[e & (2^h - 1)], applied as two multiplications
+  EPI_TABLE = 2,    // pass 1 under KZG_NTT_TWIST_TABLE=1: one multiplication by the full-table entry
+  EPI_SCALE = 3,    // single-pass inverse: n^-1 (fft_ff.py:57-58)
+};
+
 template <class F>
+struct Tw3 {
+  Fe<F> a, b, c;
+};
+
+// what a butterfly step writes back is carry-normalised (limbs < 2^L again; the value keeps growing lazily)
+template <class F>
+__device__ __forceinline__ void put_out(uint32_t* lds, uint32_t addr, const Fe<F>& v) {
+  lds_put<F>(lds, addr, Field<F>::carry(v));
+}
+
+// Fused levels (s, s+1): butterfly `rem` of line `bline` works on the positions q0 + {0, h, 2h, 3h}, h = 2^(s-1).
+template <class F>
+__device__ __forceinline__ void radix4_step(uint32_t* lds, const Tw3<F>& tw, uint32_t bline, uint32_t k, uint32_t rem,
+                                            uint32_t s) {
+  using Fd = Field<F>;
+  const uint32_t h = 1u << (s - 1);
+  const uint32_t i = rem & (h - 1), g = rem >> (s - 1);
+  const uint32_t q0 = (g << (s + 1)) + i;
+  const uint32_t a0_ = lds_addr(bline, k, q0), a1_ = lds_addr(bline, k, q0 + h);
+  const uint32_t a2_ = lds_addr(bline, k, q0 + 2 * h), a3_ = lds_addr(bline, k, q0 + 3 * h);
+  const Fe<F> x0 = lds_get<F>(lds, a0_), x2 = lds_get<F>(lds, a2_);
+  const Fe<F> t1 = Fd::mul(lds_get<F>(lds, a1_), tw.a), t3 = Fd::mul(lds_get<F>(lds, a3_), tw.a);
+  const Fe<F> b0 = Fd::add_lazy(x0, t1), b1 = Fd::sub_lazy4(x0, t1);                               // level s
+  const Fe<F> u2 = Fd::mul(Fd::add_lazy(x2, t3), tw.b), u3 = Fd::mul(Fd::sub_lazy4(x2, t3), tw.c);
+  put_out<F>(lds, a0_, Fd::add_lazy(b0, u2));                                                // level s+1
+  put_out<F>(lds, a2_, Fd::sub_lazy4(b0, u2));
+  put_out<F>(lds, a1_, Fd::add_lazy(b1, u3));
+  put_out<F>(lds, a3_, Fd::sub_lazy4(b1, u3));
+}
+
+// Levels 1 and 2: the only twiddle that is not 1 is w^(n/4) = stage[2^(kmax-2)], the same for every butterfly.
+template <class F>
+__device__ __forceinline__ void first_step(uint32_t* lds, const NttPassArgs& a, uint32_t bline, uint32_t k, uint32_t rem) {
+  using Fd = Field<F>;
+  const uint32_t q0 = rem << 2;
+  const uint32_t a0_ = lds_addr(bline, k, q0), a1_ = lds_addr(bline, k, q0 + 1);
+  const uint32_t a2_ = lds_addr(bline, k, q0 + 2), a3_ = lds_addr(bline, k, q0 + 3);
+  const Fe<F> x0 = lds_get<F>(lds, a0_), x2 = lds_get<F>(lds, a2_);
+  const Fe<F> t1 = lds_get<F>(lds, a1_), t3 = lds_get<F>(lds, a3_);
+  const Fe<F> b0 = Fd::add_lazy(x0, t1), b1 = Fd::sub_lazy4(x0, t1);
+  const Fe<F> u2 = Fd::carry(Fd::add_lazy(x2, t3));             // twiddle 1: only normalise for sub_lazy4
+  const Fe<F> u3 = Fd::mul(Fd::sub_lazy4(x2, t3), glb_get_limbs<F>(a.stage + (size_t)(1u << (a.kmax - 2)) * F::N));
+  put_out<F>(lds, a0_, Fd::add_lazy(b0, u2));
+  put_out<F>(lds, a2_, Fd::sub_lazy4(b0, u2));
+  put_out<F>(lds, a1_, Fd::add_lazy(b1, u3));
+  put_out<F>(lds, a3_, Fd::sub_lazy4(b1, u3));
+}
+
+template <class F, bool PLAIN, int EPI>
 __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   using Fd = Field<F>;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -125,28 +182,53 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   }
   const uint32_t* src = a.src + (a.batch_stride * blockIdx.y + tile * a.tile_ld) * 8;
   uint32_t* dst = a.dst + (a.batch_stride * blockIdx.y + tile * a.tile_st) * 8;
+  // element offset of (line, pos); the exchange layouts of the distributed transform (PLAIN = false) cut a
+  // line into blocks of 2^shift elements that lie `hi` elements apart
+  auto ld_off = [&](uint32_t line, uint32_t pos) -> uint64_t {
+    if constexpr (PLAIN) return line * a.ld_line + pos * a.ld_pos;
+    else return line * a.ld_line + (pos & ((1u << a.ld_shift) - 1u)) * a.ld_pos + (pos >> a.ld_shift) * a.ld_hi;
+  };
+  auto st_off = [&](uint32_t line, uint32_t pos) -> uint64_t {
+    if constexpr (PLAIN) return line * a.st_line + pos * a.st_pos;
+    else return line * a.st_line + (pos & ((1u << a.st_shift) - 1u)) * a.st_pos + (pos >> a.st_shift) * a.st_hi;
+  };
 
   // ---- load: canonical words -> limbs, bit-reversed placement inside each line
   for (uint32_t idx = tid; idx < TILE; idx += T) {
     uint32_t line, pos;
     if (a.c_fast_load) { line = idx & (C - 1); pos = idx >> logC; }
     else               { pos = idx & (LEN - 1); line = idx >> k; }
-    const uint32_t pl = pos & ((1u << a.ld_shift) - 1u), ph = pos >> a.ld_shift;
-    const uint4* g = reinterpret_cast<const uint4*>(src + (line * a.ld_line + pl * a.ld_pos + ph * a.ld_hi) * 8);
+    const uint4* g = reinterpret_cast<const uint4*>(src + ld_off(line, pos) * 8);
     const uint4 lo = g[0], hi = g[1];
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     const uint32_t rpos = k ? (__brev(pos) >> (32 - k)) : 0u;
     lds_put<F>(lds, lds_addr(line, k, rpos), Fd::from_words(w));
   }
+
+  // Butterfly bf of a fused step (levels s, s+1) works on the positions q0 + {0, h, 2h, 3h} of its line, h = 2^(s-1),
+  // with the twiddles (w^(n/2^s))^i = stage[i << (kmax - s)] of level s and stage[{i, i + h} << (kmax - s - 1)] of
+  // level s+1.  Every launch gives a tile at least TILE/4 threads: one butterfly per thread and step.
+  const uint32_t bf = tid;
+  const bool active = bf < TILE / 4;
+  const uint32_t bline = k >= 2 ? bf >> (k - 2) : 0u, rem = bf & (LEN / 4 - 1);   // rem is in range for every thread
+  auto load_tw = [&](uint32_t s) {
+    const uint32_t i = rem & ((1u << (s - 1)) - 1);
+    Tw3<F> t;
+    t.a = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s)) * F::N);
+    t.b = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s - 1)) * F::N);
+    t.c = glb_get_limbs<F>(a.stage + (size_t)((i + (1u << (s - 1))) << (a.kmax - s - 1)) * F::N);
+    return t;
+  };
   __syncthreads();
 
-  // ---- levels 1..k in LDS.  Level s merges halves of length h = 2^(s-1) with the twiddle
-  // (w^(n/2^s))^i = stage[i << (kmax - s)].
+  // ---- levels 1..k in LDS.  (Leaving the LAST step's outputs un-carried for a multiplying epilogue -- mul<5> takes
+  // such limbs -- saves 27 instructions per element and pass, but hipcc then keeps every partial sum of the step's
+  // products alive for the pinned chains of field.h and spills 1 KB per lane; measured in round 3, not kept.)
   uint32_t s = 1;
   if (k & 1u) {   // odd k: one radix-2 level first (level 1: every twiddle is w^0 = 1)
-    for (uint32_t bf = tid; bf < TILE / 2; bf += T) {
-      const uint32_t line = bf >> (k - 1);
-      const uint32_t blk = bf & (LEN / 2 - 1);
+    for (uint32_t b2 = tid; b2 < TILE / 2; b2 += T) {
+      const uint32_t line = b2 >> (k - 1);
+      const uint32_t blk = b2 & (LEN / 2 - 1);
       const uint32_t p0 = lds_addr(line, k, blk << 1), p1 = lds_addr(line, k, (blk << 1) + 1);
       const Fe<F> x = lds_get<F>(lds, p0), y = lds_get<F>(lds, p1);
       lds_put<F>(lds, p0, Fd::carry(Fd::add_lazy(x, y)));
@@ -155,40 +237,26 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     __syncthreads();
     s = 2;
   }
-  for (; s < k + 1; s += 2) {   // fused levels (s, s+1): one 4-point butterfly per thread step
-    const uint32_t h = 1u << (s - 1);
-    const bool first = (s == 1);   // level 1 twiddles and the i = 0 twiddle of level 2 are 1
-    for (uint32_t bf = tid; bf < TILE / 4; bf += T) {
-      const uint32_t line = bf >> (k - 2);
-      const uint32_t rem = bf & (LEN / 4 - 1);
-      const uint32_t i = rem & (h - 1);
-      const uint32_t g = rem >> (s - 1);
-      const uint32_t q0 = (g << (s + 1)) + i;
-      const uint32_t a0_ = lds_addr(line, k, q0), a1_ = lds_addr(line, k, q0 + h);
-      const uint32_t a2_ = lds_addr(line, k, q0 + 2 * h), a3_ = lds_addr(line, k, q0 + 3 * h);
-      const Fe<F> x0 = lds_get<F>(lds, a0_), x2 = lds_get<F>(lds, a2_);
-      Fe<F> t1 = lds_get<F>(lds, a1_), t3 = lds_get<F>(lds, a3_);
-      if (!first) {
-        const Fe<F> twa = glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s)) * F::N);
-        t1 = Fd::mul(t1, twa);
-        t3 = Fd::mul(t3, twa);
-      }
-      // level s
-      const Fe<F> b0 = Fd::add_lazy(x0, t1), b1 = Fd::sub_lazy4(x0, t1);
-      Fe<F> u2 = Fd::add_lazy(x2, t3), u3 = Fd::sub_lazy4(x2, t3);
-      // level s+1: pairs (q0, q0+2h) with twiddle index i, (q0+h, q0+3h) with index i+h
-      if (first) {
-        u2 = Fd::carry(u2);                                   // twiddle 1: only normalise for sub_lazy4
-      } else {
-        u2 = Fd::mul(u2, glb_get_limbs<F>(a.stage + (size_t)(i << (a.kmax - s - 1)) * F::N));
-      }
-      u3 = Fd::mul(u3, glb_get_limbs<F>(a.stage + (size_t)((i + h) << (a.kmax - s - 1)) * F::N));
-      lds_put<F>(lds, a0_, Fd::carry(Fd::add_lazy(b0, u2)));
-      lds_put<F>(lds, a2_, Fd::carry(Fd::sub_lazy4(b0, u2)));
-      lds_put<F>(lds, a1_, Fd::carry(Fd::add_lazy(b1, u3)));
-      lds_put<F>(lds, a3_, Fd::carry(Fd::sub_lazy4(b1, u3)));
+  if (k >= 2) {
+    Tw3<F> tw;
+    if (s == 1) {   // levels 1 and 2: the only twiddle that is not 1 is w^(n/4), the same for every butterfly
+      if (k > 2) tw = load_tw(3);   // in flight across this step's arithmetic and barrier
+      if (active) first_step<F>(lds, a, bline, k, rem);
+      __syncthreads();
+      s = 3;
+    } else {
+      tw = load_tw(2);
     }
-    __syncthreads();
+    for (; s + 2 < k + 1; s += 2) {   // every step but the last
+      const Tw3<F> cur = tw;
+      tw = load_tw(s + 2);
+      if (active) radix4_step<F>(lds, cur, bline, k, rem, s);
+      __syncthreads();
+    }
+    if (s < k + 1) {
+      if (active) radix4_step<F>(lds, tw, bline, k, rem, s);
+      __syncthreads();
+    }
   }
 
   // ---- store: the twist multiplication (or n^-1) reduces the lazy value below 2p; a factor of 1 is a plain reduction
@@ -197,28 +265,53 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     if (a.c_fast_store) { line = idx & (C - 1); pos = idx >> logC; }
     else                { pos = idx & (LEN - 1); line = idx >> k; }
     Fe<F> x = lds_get<F>(lds, lds_addr(line, k, pos));
-    if (a.twist) {
+    if constexpr (EPI == EPI_TABLE) {
       const uint64_t col = a.col_base + tile * C + line;
       // weak-normal (< 2p < 2^256) is enough between the passes: the next pass starts its lazy
       // levels from it (2p + 4p per level stays below the 64p that reduce_wide accepts)
       x = Fd::mul(x, glb_get_limbs<F>(a.twist + ((size_t)pos * a.twist_pitch + col) * F::N));
-    } else if (a.twA) {
+    } else if constexpr (EPI == EPI_FACTOR) {
+      // x * twA[hi] * twB[lo] as two multiplications (both factors canonical, so each product is back below 2p):
+      // forming the twiddle first costs the same two products plus a reduction of it
       const uint64_t e = (uint64_t)pos * (a.col_base + tile * C + line);
-      const Fe<F> tw = Fd::reduce(Fd::mul(glb_get_limbs<F>(a.twA + (size_t)(e >> a.h) * F::N),
-                                          glb_get_limbs<F>(a.twB + (size_t)(e & ((1ull << a.h) - 1)) * F::N)));
-      x = Fd::mul(x, tw);
-    } else if (a.scale) {
-      x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.scale)));      // single-pass inverse: n^-1
+      x = Fd::mul(x, glb_get_limbs<F>(a.twA + (size_t)(e >> a.h) * F::N));
+      x = Fd::mul(x, glb_get_limbs<F>(a.twB + (size_t)(e & ((1ull << a.h) - 1)) * F::N));
+    } else if constexpr (EPI == EPI_SCALE) {
+      x = Fd::reduce(Fd::mul(x, glb_get_limbs<F>(a.scale)));   // single-pass inverse: n^-1
     } else {
       x = Fd::reduce_wide(x);                                     // factor 1: reduce the lazy sum directly
     }
     uint32_t w[8];
     Fd::to_words(x, w);
-    const uint32_t pl = pos & ((1u << a.st_shift) - 1u), ph = pos >> a.st_shift;
-    uint4* g = reinterpret_cast<uint4*>(dst + (line * a.st_line + pl * a.st_pos + ph * a.st_hi) * 8);
+    uint4* g = reinterpret_cast<uint4*>(dst + st_off(line, pos) * 8);
     g[0] = make_uint4(w[0], w[1], w[2], w[3]);
     g[1] = make_uint4(w[4], w[5], w[6], w[7]);
   }
+}
+
+// one launch: picks the instantiation for the pass's layout and epilogue
+template <class F>
+int launch_pass(Ctx* c, const NttPassArgs& a, uint64_t tiles, uint32_t batch, uint32_t threads) {
+  const uint32_t tile_elems = 1u << (a.k + a.logC);
+  if (threads < tile_elems / 4 || threads > 1024) return set_err(c, KZG_ERR_ARG, "ntt: a tile needs one thread per butterfly");
+  const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
+  const bool plain = a.ld_shift == 31 && a.st_shift == 31;
+  const int epi = a.twist ? EPI_TABLE : a.twA ? EPI_FACTOR : a.scale ? EPI_SCALE : EPI_REDUCE;
+  void (*kern)(NttPassArgs) = nullptr;
+#define KZG_NTT_PICK(P, E) if (plain == P && epi == E) kern = ntt_pass_kernel<F, P, E>;
+  KZG_NTT_PICK(true, EPI_REDUCE) KZG_NTT_PICK(true, EPI_FACTOR) KZG_NTT_PICK(true, EPI_TABLE) KZG_NTT_PICK(true, EPI_SCALE)
+  KZG_NTT_PICK(false, EPI_REDUCE) KZG_NTT_PICK(false, EPI_FACTOR) KZG_NTT_PICK(false, EPI_TABLE) KZG_NTT_PICK(false, EPI_SCALE)
+#undef KZG_NTT_PICK
+  const uint32_t slot = (plain ? 0u : 4u) + (uint32_t)epi;
+  if (!(c->ntt_lds_attr_set & (1u << slot))) {   // allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per CU); per device, so per context
+    KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+    c->ntt_lds_attr_set |= (1u << slot);
+  }
+  ProfScope ps(c, "ntt_pass");
+  hipLaunchKernelGGL(kern, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
 }
 
 // out[e] = mult * base^e  (all Montgomery form), e < count
@@ -338,17 +431,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   const uint64_t n = 1ull << log_n;
   auto launch = [&](const NttPassArgs& a, uint64_t tiles) -> int {
     const uint32_t tile_elems = 1u << (a.k + a.logC);
-    const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 4));
-    const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
-    if (!c->ntt_lds_attr_set) {   // allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU); per device, so per context
-      KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      c->ntt_lds_attr_set = true;
-    }
-    ProfScope ps(c, "ntt_pass");
-    hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
-    KZG_HIP(c, hipGetLastError());
-    return KZG_OK;
+    return launch_pass<F>(c, a, tiles, batch, std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 4)));
   };
   if (log_n <= (uint32_t)TILE_LOG) {
     NttPassArgs a{};
@@ -457,17 +540,7 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
     tiles = count >> logC;
   }
   const uint32_t tile_elems = 1u << (a.k + a.logC);
-  const uint32_t threads = std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2));
-  const size_t lds_bytes = ((size_t)tile_elems * F::N + tile_elems / 32 + (1u << a.logC) + 1) * 4;
-  if (!c->ntt_lds_attr_set) {
-    KZG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<F>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->ntt_lds_attr_set = true;
-  }
-  ProfScope ps(c, "ntt_pass");
-  hipLaunchKernelGGL(ntt_pass_kernel<F>, dim3((uint32_t)tiles, 1), dim3(threads), lds_bytes, c->stream, a);
-  KZG_HIP(c, hipGetLastError());
-  return KZG_OK;
+  return launch_pass<F>(c, a, tiles, 1, std::min<uint32_t>(1024u, std::max<uint32_t>(64u, tile_elems / 2)));
 }
 
 template <class F>

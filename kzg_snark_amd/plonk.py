@@ -117,8 +117,12 @@ class Indexer:
 
 
 class Prover:
-    def __init__(self, curve_type="bn254"):
+    def __init__(self, curve_type="bn254", sharding=None):
+        """`sharding`: a sharding.ProofSharding when one proof is produced by several ranks (BASELINE config 5 on
+        more than one GPU): the commitments of a round and the two openings are dealt over the ranks against a
+        replicated key, and every rank returns the same proof."""
         self.kzg = KZG(curve_type)
+        self.sharding = sharding
 
     def prove(self, ipk, x, w, blinders=None, trace=None):
         """`blinders` (tests only) fixes b1..b11 of plonk/prover.py:72-75 and :346; `trace`, when a
@@ -138,11 +142,17 @@ class Prover:
         PI = dom.public_input_poly(R, x)
         b = [Fq.random_element() for _ in range(11)] if blinders is None else [Fq(v) for v in blinders]
         assert len(b) == 11
+        sh = self.sharding
+        if sh is not None and sh.world > 1:
+            b = [Fq(v) for v in sh.shared_scalars([int(v) for v in b])]              # drawn once, by rank 0
+
+        def commit(polys):                                                          # plonk/prover.py:89,113,136
+            return kzg.commit(ck, polys) if sh is None else sh.commit_batch(lambda ps: kzg.commit(ck, ps), polys)
 
         # round 1: wire polynomials (3 INTTs, 3 MSMs of degree n+1)
         wires = [(b[2 * i] * X + b[2 * i + 1]) * ZH + dom.interpolate(cols[i]) for i in range(3)]
         a_p, b_p, c_p = wires
-        wire_comms = kzg.commit(ck, wires)
+        wire_comms = commit(wires)
         tr.append_message("round1-commitments", wire_comms)
         beta, gamma = tr.get_challenge("beta"), tr.get_challenge("gamma")
 
@@ -155,7 +165,7 @@ class Prover:
                 den *= col[i] + beta * sstar[blk * n + i] + gamma
             acc.append(acc[-1] * num / den)
         z_p = (b[6] * X * X + b[7] * X + b[8]) * ZH + dom.interpolate(acc)
-        z_comm = kzg.commit(ck, [z_p])[0]
+        z_comm = commit([z_p])[0]
         tr.append_message("round2-commitment", z_comm)
         alpha = tr.get_challenge("alpha")
 
@@ -173,7 +183,7 @@ class Prover:
         t_lo = R(tc[:n]) + b[9] * X ** n
         t_mid = R(tc[n:2 * n]) - b[9] + b[10] * X ** n
         t_hi = R(tc[2 * n:3 * n + 6]) - b[10]
-        t_comms = kzg.commit(ck, [t_lo, t_mid, t_hi])
+        t_comms = commit([t_lo, t_mid, t_hi])
         tr.append_message("round3-commitments", t_comms)
         zeta = tr.get_challenge("zeta")
 
@@ -195,8 +205,9 @@ class Prover:
         if trace is not None:
             trace.update(beta=beta, gamma=gamma, alpha=alpha, zeta=zeta, v=v, evaluations=dict(ev), a=a_p, b=b_p,
                          c=c_p, z=z_p, PI=PI, t=t_p, t_lo=t_lo, t_mid=t_mid, t_hi=t_hi, r=r_p)
-        W_z = kzg.open(ck, [r_p, a_p, b_p, c_p, P["S_sigma1"], P["S_sigma2"]], zeta, v)
-        W_zw = kzg.open(ck, [z_p], zeta * g, v)
+        opens = [lambda: kzg.open(ck, [r_p, a_p, b_p, c_p, P["S_sigma1"], P["S_sigma2"]], zeta, v),   # plonk/prover.py:184
+                 lambda: kzg.open(ck, [z_p], zeta * g, v)]                                               # :185
+        W_z, W_zw = [f() for f in opens] if sh is None else sh.run_dealt(opens)
         return {"commitments": dict(zip(("a", "b", "c"), wire_comms), z=z_comm,
                                     t_lo=t_comms[0], t_mid=t_comms[1], t_hi=t_comms[2]),
                 "evaluations": ev,

@@ -171,9 +171,15 @@ class DeviceIndexer:
 
 
 class DeviceProver:
-    def __init__(self, curve_type="bls12_381", alg=None):
+    def __init__(self, curve_type="bls12_381", alg=None, sharding=None):
+        """`sharding`: a sharding.ProofSharding when one proof is produced by several ranks, one GPU each
+        (BASELINE config 5 on more than one GPU): every rank runs the vector work of the rounds on its own copy
+        of the polynomials, the MSMs of a round -- 3 + 1 + 3 commitments (plonk/prover.py:89,113,136) and the two
+        openings (:184-185) -- are dealt round-robin against the replicated key, and one all-gather of 97-byte
+        records per round gives every rank the same points, hence the same challenges and the same proof."""
         self.kzg = KZG(curve_type)
         self.alg = alg or DeviceAlgebra(curve_type)
+        self.sharding = sharding
         self._dom_cache = {}                     # (n, g) -> device vectors of that evaluation domain (one entry)
 
     def _domain_constants(self, n, g):
@@ -213,19 +219,27 @@ class DeviceProver:
     def _commit_begin(self, ck, tensors):
         """Queue the commitments of a round on the library's pipeline and return at once: whatever the prover
         enqueues next that does not need the round's challenge runs beside the MSMs (they are instruction-issue
-        bound, the vector work is HBM-bound)."""
-        alg = self.alg
-        stride = max(t.shape[0] for t in tensors)
-        pack = torch.stack([alg.padded(t, stride) for t in tensors]).contiguous()
-        xy = np.zeros((len(tensors), 2 * alg.ctx.fp_limbs), dtype=np.uint64)
-        inf = np.zeros(len(tensors), dtype=np.uint8)
-        alg.ctx.commit_device_async(ck.srs, pack.data_ptr(), [t.shape[0] for t in tensors], stride, xy, inf)
-        return pack, xy, inf
+        bound, the vector work is HBM-bound).  With several ranks only this rank's share of the round is queued."""
+        alg, sh = self.alg, self.sharding
+        k = len(tensors)
+        mine = list(range(k)) if sh is None else sh.mine(k)
+        if not mine:
+            return None, None, None, mine, k
+        own = [tensors[i] for i in mine]
+        stride = max(t.shape[0] for t in own)
+        pack = torch.stack([alg.padded(t, stride) for t in own]).contiguous()
+        xy = np.zeros((len(own), 2 * alg.ctx.fp_limbs), dtype=np.uint64)
+        inf = np.zeros(len(own), dtype=np.uint8)
+        alg.ctx.commit_device_async(ck.srs, pack.data_ptr(), [t.shape[0] for t in own], stride, xy, inf)
+        return pack, xy, inf, mine, k
 
     def _commit_end(self, handle):
-        _, xy, inf = handle
+        _, xy, inf, mine, k = handle
         self.alg.ctx.commit_flush()
-        return self.kzg._points(xy, inf)
+        local = self.kzg._points(xy, inf) if mine else []
+        if self.sharding is None:
+            return local
+        return self.sharding.gather_points(dict(zip(mine, local)), k)      # the round's one exchange
 
     def _blind(self, coeffs, n, blinders):
         """coeffs (length n) + (b_k X^k + ... + b_0) * (X^n - 1): length n + len(blinders)."""
@@ -242,7 +256,20 @@ class DeviceProver:
         """plonk/prover.py:24-212.  `blinders` (tests only) fixes b1..b11 of plonk/prover.py:72-75 and
         :346 in the reference's order; `trace`, when a dict, receives the challenges and the device
         tensors of every intermediate polynomial so a test can compare them with the oracle."""
+        try:
+            return self._prove(ipk, x, w, blinders, trace)
+        except BaseException:
+            # a proof that fails half way (an assert of the protocol, an allocation) must not leave commitments of
+            # its rounds queued in the library's pipeline: drain it before the error travels on
+            try:
+                self.alg.ctx.commit_flush()
+            except Exception:
+                pass
+            raise
+
+    def _prove(self, ipk, x, w, blinders, trace):
         kzg, Fq, alg = self.kzg, self.kzg.Fq, self.alg
+        sh = self.sharding
         r = kzg.curve_order
         ck, C = ipk["ck"], ipk["coeffs"]
         sub = ipk["subgroups"]
@@ -271,16 +298,24 @@ class DeviceProver:
             return alg.upload_parts(n, parts)
         b = [int(Fq.random_element()) for _ in range(11)] if blinders is None else [int(v) % r for v in blinders]
         assert len(b) == 11
+        if sh is not None and sh.world > 1:
+            b = sh.shared_scalars(b)                                          # drawn once, by rank 0
+        dealt = sh is not None and sh.world > 1 and sh.deal_transforms
         D = self._domain_constants(n, g)
         ones, idH = D["ones"], D["idH"]                                       # 1 and g^i on H
 
         # round 1
         vals = [column(i) for i in range(3)]
-        wires = [self._blind(alg.ntt(v.clone(), g, True), n, [b[2 * i + 1], b[2 * i]]) for i, v in enumerate(vals)]
-        a_c, b_c, c_c = wires
         pi = alg.zeros(n)                                                    # PI values: -x_i on the first rows
         if len(x):
             pi[:len(x)] = alg.upload([(-int(v)) % r for v in x])
+        if dealt:   # the four independent INTTs of the round, each on its owner, results broadcast
+            srcs = vals + [pi]
+            co = sh.dealt_tensors([(n, 4)] * 4, lambda i: alg.ntt(srcs[i].clone(), g, True), vals[0])
+        else:
+            co = [alg.ntt(v.clone(), g, True) for v in vals] + [None]
+        wires = [self._blind(co[i], n, [b[2 * i + 1], b[2 * i]]) for i in range(3)]
+        a_c, b_c, c_c = wires
         h1 = self._commit_begin(ck, wires)
         # queued behind the round-1 MSMs, needing no challenge: the wires and PI on the coset K * H', |H'| = 4n,
         # and the gate constraint
@@ -290,8 +325,13 @@ class DeviceProver:
         def on_coset(coeffs):
             return alg.ntt(alg.mul_powers(alg.padded(coeffs, N4), K), w4, False)
 
-        PI_c = alg.ntt(pi, g, True)
-        E = {k: on_coset(v) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("PI", PI_c))}
+        PI_c = co[3] if dealt else alg.ntt(pi, g, True)
+        r1 = (("a", a_c), ("b", b_c), ("c", c_c), ("PI", PI_c))
+        if dealt:   # and their four coset NTTs
+            ev4 = sh.dealt_tensors([(N4, 4)] * 4, lambda i: on_coset(r1[i][1]), vals[0])
+            E = {k: t for (k, _), t in zip(r1, ev4)}
+        else:
+            E = {k: on_coset(v) for k, v in r1}
         E.update(self._circuit_cosets(ipk, on_coset))
         gate = alg.add(alg.add(alg.mul(alg.mul(E["a"], E["b"]), E["qM"]), alg.mul(E["a"], E["qL"])),
                        alg.add(alg.mul(E["b"], E["qR"]), alg.mul(E["c"], E["qO"])))
@@ -384,12 +424,15 @@ class DeviceProver:
         L = alg.ctx.fp_limbs
         o1 = (np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros(4, dtype=np.uint64))
         o2 = (np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8), np.zeros(4, dtype=np.uint64))
-        alg.ctx.open_device_async(ck.srs, pack.data_ptr(), [p.shape[0] for p in polys], stride, zw_(zeta), zw_(v), *o1)
+        mine = [0, 1] if sh is None else sh.mine(2)                          # with several ranks: one opening each
+        if 0 in mine:
+            alg.ctx.open_device_async(ck.srs, pack.data_ptr(), [p.shape[0] for p in polys], stride, zw_(zeta), zw_(v), *o1)
         zpack = alg.padded(z_c, stride)
-        alg.ctx.open_device_async(ck.srs, zpack.data_ptr(), [z_c.shape[0]], stride, zw_(zeta * int(g) % r), zw_(v), *o2)
+        if 1 in mine:
+            alg.ctx.open_device_async(ck.srs, zpack.data_ptr(), [z_c.shape[0]], stride, zw_(zeta * int(g) % r), zw_(v), *o2)
         alg.ctx.commit_flush()
-        W_z = kzg._points(o1[0], o1[1])[0]
-        W_zw = kzg._points(o2[0], o2[1])[0]
+        local = {i: kzg._points(o[0], o[1])[0] for i, o in ((0, o1), (1, o2)) if i in mine}
+        W_z, W_zw = (local[0], local[1]) if sh is None else sh.gather_points(local, 2)
         return {"commitments": dict(zip(("a", "b", "c"), wire_comms), z=z_comm,
                                     t_lo=t_comms[0], t_mid=t_comms[1], t_hi=t_comms[2]),
                 "evaluations": evF,

@@ -171,6 +171,104 @@ class DistributedCommitter:
         return acc
 
 
+class ProofSharding:
+    """BASELINE config 5 on more than one GPU: ONE PLONK proof (plonk/prover.py:24-212) over G ranks.
+
+    Every rank holds the circuit, the witness and a replicated commitment key and walks through the same rounds;
+    what a round is made of -- its MSMs -- is dealt:
+      * the commitments of a round (plonk/prover.py:89,113,136: 3 + 1 + 3) round-robin over the ranks, item i to
+        rank i mod G, each rank running whole MSMs on its own commit pipeline (`commit_batch`);
+      * the two opening proofs (plonk/prover.py:184-185), one per rank (`run_dealt`);
+      * optionally (`deal_transforms`) the independent transforms of round 1 -- the INTTs of the wire columns and of
+        PI and their coset NTTs -- each computed by its owner and broadcast (`dealt_tensors`).  Off by default: a
+        2^20-element INTT takes 0.11 ms on one MI355X while its 32 MiB result costs more than that to move over
+        one xGMI link (about 0.2 ms at 153 GB/s), so replicated transforms are the faster plan; the MSMs (2.3 ms
+        each, 97-byte results) are what pays to deal.
+    After every exchange all ranks hold the same points, so they derive the same Fiat-Shamir challenges and end
+    with the same proof dict.  What crosses ranks is one all-gather of fixed-size records per round (pack_point),
+    plus one broadcast per dealt transform."""
+
+    def __init__(self, group=None, deal_transforms=False):
+        self.group = group
+        self.deal_transforms = bool(deal_transforms)
+        self.exchanges = 0          # collectives issued (tests / bench bookkeeping)
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def owner(self, i):
+        return i % self.world
+
+    def mine(self, k):
+        """indices of the k items of a round that this rank computes"""
+        return [i for i in range(k) if i % self.world == self.rank]
+
+    def shared_scalars(self, values):
+        """Rank 0's list of field elements on every rank: the blinding scalars of a proof (plonk/prover.py:72-75,
+        :346) are drawn once, not per rank."""
+        payload = b"".join(int(v).to_bytes(FR_BYTES, "little") for v in values)
+        self.exchanges += 1
+        blob = all_gather_bytes(payload, self.group)[0]
+        return [int.from_bytes(blob[i * FR_BYTES:(i + 1) * FR_BYTES], "little") for i in range(len(values))]
+
+    def gather_points(self, local, k):
+        """local: {item index: point} for this rank's items of a round of k.  Returns the k points on every rank.
+        One all-gather of ceil(k / G) records per rank (absent slots flagged)."""
+        world, rank = self.world, self.rank
+        per_rank = (k + world - 1) // world
+        payload = b"".join(pack_point(local.get(rank + j * world)) for j in range(per_rank))
+        self.exchanges += 1
+        out = [None] * k
+        for g, blob in enumerate(all_gather_bytes(payload, self.group)):
+            for j in range(per_rank):
+                pt = unpack_point(blob[j * POINT_BYTES:(j + 1) * POINT_BYTES])
+                if pt is not None:
+                    out[g + j * world] = pt
+        assert all(p is not None for p in out), "a rank did not deliver its share of the round"
+        return out
+
+    def commit_batch(self, commit_fn, polynomials):
+        """commit_fn(list of polynomials) -> list of points on this rank's GPU (KZG.commit against the replicated
+        key).  Every rank passes the same list; returns all commitments, in order, on every rank."""
+        k = len(polynomials)
+        mine = self.mine(k)
+        local = commit_fn([polynomials[i] for i in mine]) if mine else []
+        return self.gather_points(dict(zip(mine, local)), k)
+
+    def run_dealt(self, thunks):
+        """thunks: k callables each returning one point (e.g. the two KZG.open calls); thunk i runs on rank i mod G."""
+        mine = self.mine(len(thunks))
+        return self.gather_points({i: thunks[i]() for i in mine}, len(thunks))
+
+    def dealt_tensors(self, shapes, compute, like):
+        """k independent transforms: compute(i) -> int64 tensor of shape shapes[i] on the owner; every rank returns
+        the list of all k results (one broadcast per item from its owner; RCCL moves device tensors, gloo host
+        copies).  `like` supplies device and dtype for the receive buffers."""
+        out = []
+        on_gpu = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        for i, shape in enumerate(shapes):
+            own = self.owner(i) == self.rank
+            t = compute(i) if own else torch.empty(shape, dtype=like.dtype, device=like.device)
+            if self.world > 1:
+                self.exchanges += 1
+                src = dist.get_global_rank(self.group, self.owner(i)) if self.group is not None else self.owner(i)
+                if t.is_cuda and not on_gpu:         # rehearsal on one GPU: gloo moves host memory only
+                    torch.cuda.synchronize(t.device)
+                    host = t.cpu()
+                    dist.broadcast(host, src=src, group=self.group)
+                    if not own:
+                        t.copy_(host)
+                else:                                # RCCL orders the broadcast after the current torch stream's work
+                    dist.broadcast(t, src=src, group=self.group)
+            out.append(t)
+        return out
+
+
 class DistributedNTT:
     """Four-step NTT / INTT of n = 2^log_n = N1*N2 elements (N1 = 2^ceil(log_n/2)) over G ranks,
     G | N1 and G | N2.  Input: natural order, rank g holds the contiguous range

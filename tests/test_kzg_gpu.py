@@ -540,3 +540,83 @@ def test_limb_buffers_are_accepted_like_lists(native, kzgs, small_keys, curve):
         kzg.commit(ck, [too_long])
     padded = np.concatenate([bufs[0], np.zeros((9, 4), dtype=np.uint64)])                         # degree 63 with zero padding
     assert kzg.commit(ck, [padded]) == kzg.commit(ck, [polys[0]])
+
+
+@pytest.mark.parametrize("curve,n", [("bn254", (1 << 18) + 5), ("bls12_381", 1 << 20)])
+def test_caller_supplied_key_at_size_through_srs_load_g1(native, kzgs, curve, n):
+    """kzg_srs_load_g1 is the entry a reference-side binding calls with its `ck` list (kzg.py:80,112-116).  At
+    the sizes that take the 20-bit-window table: export a generated key, set a few points to infinity (flag) and
+    make a few duplicates, import the arrays, commit, and compare with the trapdoor value of the EDITED key:
+    sum_i c_i * tau^e(i) * G1 with the removed terms left out and duplicated points counted at their source's
+    exponent.  Also re-exports the imported key and compares it with what went in."""
+    cv = O.curve(curve)
+    r = cv.r
+    ctx = native.get_context(curve)
+    tau = 0x5eed5eed5eed5eed1234 % r
+    gen = ctx.srs_generate(native.int_to_words(tau), n)
+    xy, inf = gen.export()
+    gen.close()
+    assert inf.sum() == 0
+    removed = [0, 7, 4097, n // 2, n - 1]                      # points at infinity in the caller's list
+    dup = {5: 3, 100001: 100000, n - 2: 1}                     # ck[dst] = ck[src]
+    for i in removed:
+        inf[i] = 1
+        xy[i] = 0
+    for dst, src in dup.items():
+        xy[dst] = xy[src]
+    srs = ctx.srs_load_g1(xy, inf)
+    xy2, inf2 = srs.export()
+    assert np.array_equal(inf2, inf) and np.array_equal(xy2[inf == 0], xy[inf == 0])
+    rs = np.random.RandomState(n % 997)
+    raw = rs.randint(0, 1 << 62, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] >>= np.uint64(4)
+    coeffs = native.limbs_to_ints(raw)
+    got_xy, got_inf = ctx.commit(srs, raw.reshape(1, n, 4), [n], n)
+    L = ctx.fp_limbs
+    got = native.limbs_to_ints(got_xy.reshape(2, L))
+    # exponent-wise: sum c_i tau^i, minus removed terms, with duplicates re-pointed
+    total = O.poly_eval(coeffs, tau, r)
+    for i in removed:
+        total -= coeffs[i] * pow(tau, i, r)
+    for dst, src in dup.items():
+        total += coeffs[dst] * (pow(tau, src, r) - pow(tau, dst, r))
+    want = O.normalize(O.multiply(O.from_affine(cv.g1), total % r, cv), cv)
+    assert got_inf[0] == 0 and (got[0], got[1]) == want
+    srs.close()
+
+
+def test_commit_2_20_with_extreme_coefficients(native, kzgs):
+    """Scalars that stress the 13-window signed-digit recode at the BASELINE size: r-1, the whole run
+    r-2^20 .. r-1, values whose every 20-bit window is 2^19 (the digit that carries) or 2^20-1, 2^255-adjacent
+    values reduced below r, and powers of two on window boundaries -- beside uniform ones over [0, r).  Trapdoor
+    identity commit(ck, p) == p(tau)*G1 (kzg.py:112-116)."""
+    cv = O.BLS12_381
+    r = cv.r
+    kzg = kzgs["bls12_381"]
+    n = 1 << 20
+    tau = 0x6b7a675f736e61726b7a675f736e6172 % r
+    ck, _ = kzg.setup(n - 1, tau=tau)
+    rs = np.random.RandomState(31)
+    raw = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2)
+    raw[:, 3] %= np.uint64(r >> 192)                                          # uniform-ish over [0, r)
+    special = [r - 1 - i for i in range(1 << 12)]                             # r-1 downwards
+    special += [r - (1 << 20) + i for i in range(1 << 12)]                    # r-2^20 upwards
+    half = sum(1 << (20 * j + 19) for j in range(13)) % r                     # every window = 2^19
+    ones = sum(((1 << 20) - 1) << (20 * j) for j in range(13)) % r            # every window = 2^20-1
+    special += [half, ones, (1 << 255) % r, ((1 << 255) - 1) % r, ((1 << 255) - 19) % r, (1 << 254), (1 << 254) - 1]
+    special += [1 << (20 * j) for j in range(13)] + [(1 << (20 * j)) - 1 for j in range(1, 13)]
+    special += [(1 << (20 * j + 19)) for j in range(12)]
+    pos = rs.choice(n, size=len(special), replace=False)
+    raw[pos] = native.ints_to_limbs(special)
+    coeffs = native.limbs_to_ints(raw)
+    ctx = native.get_context("bls12_381")
+    xy, inf = ctx.commit(ck.srs, raw.reshape(1, n, 4), [n], n)
+    got = native.limbs_to_ints(xy.reshape(2, 6))
+    assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+    # the special values alone (everything else zero: the zero-skip of kzg.py:113-114 at size)
+    sparse = np.zeros_like(raw)
+    sparse[pos] = raw[pos]
+    xy, inf = ctx.commit(ck.srs, sparse.reshape(1, n, 4), [n], n)
+    got = native.limbs_to_ints(xy.reshape(2, 6))
+    sp = native.limbs_to_ints(sparse)
+    assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(sp, tau, cv), cv)

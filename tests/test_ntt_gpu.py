@@ -302,3 +302,69 @@ def test_ragged_lengths_at_size(native, curve, n):
         want = raw.copy()
         CO.fft(curve, want, w, inverse=inverse)
         assert np.array_equal(got, want), (n, inverse)
+
+
+def _uniform_below_r(rs, n, r):
+    """uint64[n,4] limbs of values spread over the WHOLE range [0, r): random 256-bit words with the top limb
+    folded below r's top limb (+1 where the lower limbs allow it), so near-r values occur -- the at-size inputs
+    of the older tests stop at 2^253."""
+    raw = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) \
+        + rs.randint(0, 2, size=(n, 4)).astype(np.uint64)
+    top = r >> 192
+    raw[:, 3] %= np.uint64(top)                      # value < top * 2^192 <= r
+    return raw
+
+
+def _plant_edge_values(raw, r, native):
+    n = raw.shape[0]
+    edge = [r - 1, r - 2, 0, 1, r - (1 << 20), (r - 1) // 2, (r + 1) // 2, r - 1]
+    pos = [0, 1, 2, 3, n // 2, n // 2 + 1, n - 2, n - 1]
+    raw[pos] = native.ints_to_limbs(edge)
+    return raw
+
+
+@pytest.mark.parametrize("curve,log_n", [("bls12_381", 20), ("bn254", 20), ("bls12_381", 24)])
+def test_elementwise_against_the_c_oracle_at_size(native, curve, log_n):
+    """BASELINE config 2 ("bit-exact vs fft_ff.py" at 2^20) and the config-4 size: every output element of the
+    forward and of the inverse transform against oracle/kzg_oracle.c, which runs the recursion of
+    fft_ff.py:15-37 (and :51-58) as written.  Inputs cover the whole range [0, r) with r-1, r-2, 0, 1, r-2^20
+    planted, so near-r limbs go through all lazy levels of both passes and the factor-table twist."""
+    from oracle import c_oracle as CO
+    cv = O.curve(curve)
+    n = 1 << log_n
+    w = cv.root_of_unity(n)
+    raw = _plant_edge_values(_uniform_below_r(np.random.RandomState(100 + log_n), n, cv.r), cv.r, native)
+    ctx = native.get_context(curve)
+    for inverse in (False, True):
+        got = raw.copy()
+        ctx.ntt(got, log_n, native.int_to_words(w), inverse)
+        want = raw.copy()
+        CO.fft(curve, want, w, inverse=inverse)
+        assert np.array_equal(got, want), (curve, log_n, inverse)
+
+
+@pytest.mark.parametrize("log_n,cases", [(12, "all"), (20, "all"), (24, "two")])
+def test_worst_case_values_through_the_lazy_levels(native, log_n, cases):
+    """The lazy butterflies let values grow by 4p per level (ntt.hip header: <= 49p after the 12 levels of a
+    single pass).  Vectors that maximise that growth -- all r-1, alternating 0 / r-1 -- with a primitive root and
+    with w = r-1 (order 2: every twiddle is +-1), at the single-pass limit 2^12, at 2^20 and at 2^24, element by
+    element against the C restatement of fft_ff.py:15-37."""
+    from oracle import c_oracle as CO
+    cv = O.BLS12_381
+    r = cv.r
+    n = 1 << log_n
+    top = native.ints_to_limbs([r - 1])[0]
+    vec_all = np.tile(top, (n, 1))
+    vec_alt = np.zeros((n, 4), dtype=np.uint64)
+    vec_alt[1::2] = top
+    combos = [(vec_all, cv.root_of_unity(n), False), (vec_alt, cv.root_of_unity(n), False),
+              (vec_all, r - 1, False), (vec_alt, r - 1, True)]
+    if cases == "two":
+        combos = [combos[1], combos[2]]
+    ctx = native.get_context("bls12_381")
+    for vec, w, inverse in combos:
+        got = vec.copy()
+        ctx.ntt(got, log_n, native.int_to_words(w), inverse)
+        want = vec.copy()
+        CO.fft("bls12_381", want, w, inverse=inverse)
+        assert np.array_equal(got, want), (log_n, hex(w)[:12], inverse)

@@ -149,6 +149,45 @@ struct OpLshlAdd64 {
   }
 };
 
+
+// ---- round 3: the simple 32-bit integer ops the field code's bookkeeping is made of ----
+#define SIMPLE_OP(NAME, TEXT, ASM)                                                       \
+  struct NAME {                                                                          \
+    static constexpr const char* name = TEXT;                                            \
+    __device__ static void run(uint64_t (&a)[CH], uint32_t x, uint32_t y) {              \
+      _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                   \
+        uint32_t t = (uint32_t)a[c];                                                     \
+        asm volatile(ASM : "+v"(t) : "v"(x), "v"(y));                                    \
+        a[c] = t;                                                                        \
+      }                                                                                  \
+    }                                                                                    \
+  };
+SIMPLE_OP(OpAddU32, "v_add_u32(asm)", "v_add_u32 %0, %0, %1")
+SIMPLE_OP(OpSubU32, "v_sub_u32(asm)", "v_sub_u32 %0, %0, %1")
+SIMPLE_OP(OpAndB32, "v_and_b32(asm)", "v_and_b32 %0, %0, %1")
+SIMPLE_OP(OpOrB32, "v_or_b32(asm)", "v_or_b32 %0, %0, %1")
+SIMPLE_OP(OpXorB32, "v_xor_b32(asm)", "v_xor_b32 %0, %0, %1")
+SIMPLE_OP(OpLshr, "v_lshrrev_b32(asm)", "v_lshrrev_b32 %0, 3, %0")
+SIMPLE_OP(OpLshl, "v_lshlrev_b32(asm)", "v_lshlrev_b32 %0, 3, %0")
+SIMPLE_OP(OpAshr, "v_ashrrev_i32(asm)", "v_ashrrev_i32 %0, 3, %0")
+SIMPLE_OP(OpMov, "v_mov_b32(asm)", "v_mov_b32 %0, %1")
+SIMPLE_OP(OpBfe, "v_bfe_u32(asm)", "v_bfe_u32 %0, %0, 3, 29")
+SIMPLE_OP(OpAlignbit, "v_alignbit_b32(asm)", "v_alignbit_b32 %0, %0, %1, 29")
+SIMPLE_OP(OpAndOr, "v_and_or_b32(asm)", "v_and_or_b32 %0, %0, %1, %2")
+SIMPLE_OP(OpLshlAdd32, "v_lshl_add_u32(asm)", "v_lshl_add_u32 %0, %0, 3, %1")
+SIMPLE_OP(OpAddLshl, "v_add_lshl_u32(asm)", "v_add_lshl_u32 %0, %0, %1, 3")
+SIMPLE_OP(OpLshlOr, "v_lshl_or_b32(asm)", "v_lshl_or_b32 %0, %0, 3, %1")
+SIMPLE_OP(OpCndmask, "v_cndmask_b32(asm)", "v_cndmask_b32 %0, %0, %1, vcc")
+SIMPLE_OP(OpMulU24, "v_mul_u32_u24(asm)", "v_mul_u32_u24 %0, %0, %1")
+SIMPLE_OP(OpMaxU32, "v_max_u32(asm)", "v_max_u32 %0, %0, %1")
+SIMPLE_OP(OpPkAddU16, "v_pk_add_u16(asm)", "v_pk_add_u16 %0, %0, %1")
+SIMPLE_OP(OpAddF32, "v_add_f32(asm)", "v_add_f32 %0, %0, %1")
+SIMPLE_OP(OpAddCoOnly, "v_add_co_u32(asm)", "v_add_co_u32 %0, vcc, %0, %1")
+SIMPLE_OP(OpSubrevCo, "v_subb_co_u32(asm)", "v_subb_co_u32 %0, vcc, %0, %1, vcc")
+SIMPLE_OP(OpPerm, "v_perm_b32(asm)", "v_perm_b32 %0, %0, %1, %2")
+SIMPLE_OP(OpDot4, "v_dot4_u32_u8(asm)", "v_dot4_u32_u8 %0, %0, %1, %2")
+SIMPLE_OP(OpMadU16, "v_mad_u32_u16(asm)", "v_mad_u32_u16 %0, %0, %1, %2")
+
 template <class Op>
 __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t x, uint32_t y) {
   uint64_t a[CH];
@@ -205,6 +244,18 @@ int main() {
     if (bench<OpFma64>(d_out, blocks, 1)) return 1;
     if (bench<OpMul64f>(d_out, blocks, 1)) return 1;
   }
+  printf("--- round 3: simple 32-bit integer ops, 8 waves/SIMD ---\n");
+#define RUN(OP) if (bench<OP>(d_out, blocks, 1)) return 1;
+  RUN(OpFma32) RUN(OpAddF32) RUN(OpAddU32) RUN(OpSubU32) RUN(OpAndB32) RUN(OpOrB32) RUN(OpXorB32) RUN(OpLshr) RUN(OpLshl)
+  RUN(OpAshr) RUN(OpMov) RUN(OpBfe) RUN(OpAlignbit) RUN(OpAndOr) RUN(OpLshlAdd32) RUN(OpAddLshl) RUN(OpLshlOr)
+  RUN(OpCndmask) RUN(OpMulU24) RUN(OpMaxU32) RUN(OpPkAddU16) RUN(OpAddCoOnly) RUN(OpSubrevCo) RUN(OpPerm) RUN(OpDot4)
+  RUN(OpMadU16) RUN(OpAdd3) RUN(OpMad64Pure)
+  printf("--- 4 waves/SIMD ---\n");
+  blocks = 256 * 4;
+  RUN(OpFma32) RUN(OpAddU32) RUN(OpAndB32) RUN(OpLshr) RUN(OpAdd3) RUN(OpMad64Pure)
+  printf("--- 2 waves/SIMD ---\n");
+  blocks = 256 * 2;
+  RUN(OpFma32) RUN(OpAddU32) RUN(OpAndB32) RUN(OpLshr) RUN(OpAdd3) RUN(OpMad64Pure)
   // one wave per SIMD variant (latency-exposed)
   printf("--- 1 block/CU (1 wave/SIMD) ---\n");
   if (bench<OpMad64Pure>(d_out, 256, 1)) return 1;

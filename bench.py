@@ -283,6 +283,23 @@ class Env:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def collectives_info(self):
+        """Backend, the world size torch.distributed reports, and the device every rank sits on (gathered)."""
+        dist, torch = self.dist, self.torch
+        if not self.collective:
+            return {"backend": None, "world_size_seen": 1, "device_per_rank": [str(self.dev)]}
+        mine = f"{self.dev}:{torch.cuda.get_device_properties(self.dev).name}".encode()[:63].ljust(64, b" ")
+        from kzg_snark_amd.sharding import all_gather_bytes
+        return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                "device_per_rank": [b.decode().strip() for b in all_gather_bytes(mine, always=True)]}
+
+    def build_info(self):
+        """Whether this process's library was compiled in this checkout state or reused as shipped."""
+        from kzg_snark_amd import build as B
+        st = B._read_stamp()
+        return {"library": os.path.relpath(self.native.LIB_PATH, ROOT), "source_hash": st.get("source_hash", "")[:16],
+                "matches_sources": st.get("source_hash") == B.source_hash(), "hipcc": st.get("hipcc")}
+
     def affine(self, pt):
         q = self.kzg._g1.normalize(pt)
         return (int(q[0]), int(q[1]))
@@ -353,6 +370,14 @@ def section_open(env, srs, n):
     ok_ev = Pz == sum(pow(xi, i + 1, r) * ctx.poly_eval(lens[i], polys[i].data_ptr(), z) for i in range(k)) % r
     alg_bytes = (k + 1) * n * 32                            # read k polynomials, write the quotient
     avg_s = poly_ms / max(poly_cnt, 1) * 1e-3
+    # HBM bytes per opening from the PMC passes of tools/profile_open.sh (profiles/counters.json "open_poly"); only
+    # quoted for the configuration they were collected on
+    traffic = None
+    cfile = os.path.join(ROOT, "profiles", "counters.json")
+    if os.path.exists(cfile):
+        ent = json.load(open(cfile)).get("open_poly") or {}
+        if ent.get("k") == k and ent.get("log_n") == n.bit_length() - 1:
+            traffic = ent.get("hbm_bytes")
     return {
         "value": env.world * iters / elapsed, "unit": "opens/s", "k": k, "log_n": n.bit_length() - 1,
         "ms_per_open": elapsed / iters * 1e3,
@@ -363,7 +388,7 @@ def section_open(env, srs, n):
         "verified": {"proof_trapdoor": bool(ok), "combined_eval": bool(ok_ev), "pipelined_equals_synchronous": bool(ok_async)},
         "roofline": {"kernel": "open_poly: lincomb + chunk_eval + scan + chunk_fill (csrc/poly.hip)", "bound": "hbm",
                      "achieved": alg_bytes / avg_s / 1e9 if avg_s > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBPS if avg_s > 0 else None, "traffic": None,
+                     "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBPS if avg_s > 0 else None, "traffic": traffic,
                      "algorithmic_bytes_per_open": alg_bytes},
     }, bool(ok and ok_ev and ok_async)
 
@@ -457,7 +482,11 @@ def section_plonk(env):
     emits), median of three after the first; the verifier must accept the last proof."""
     torch = env.torch
     from kzg_snark_amd import plonk, plonk_device
+    from kzg_snark_amd.sharding import ProofSharding
     n = 1 << env.args.plonk_log_n
+    # N > 1: ONE proof over the ranks -- the commitments of a round and the two openings dealt round-robin against
+    # the replicated key, vector work replicated (sharding.ProofSharding); every rank ends with the same proof
+    sh = ProofSharding() if env.collective else None
     prev = torch.cuda.current_stream(env.dev)
     t = {}
     t0 = time.perf_counter()
@@ -465,28 +494,43 @@ def section_plonk(env):
     t["circuit_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     idx = plonk_device.DeviceIndexer(env.args.curve)
-    ipk, ivk = idx.preprocess(qM, qL, qR, qO, qC, perm)
+    ipk, ivk = idx.preprocess(qM, qL, qR, qO, qC, perm, tau=0x706c6f6e6b if sh else None)   # one key on every rank
     t["index_s"] = time.perf_counter() - t0
-    prv = plonk_device.DeviceProver(env.args.curve, alg=idx.alg)
+    prv = plonk_device.DeviceProver(env.args.curve, alg=idx.alg, sharding=sh)
+    env.barrier()
     t0 = time.perf_counter()
     proof = prv.prove(ipk, x, w)
     t["prove_first_s"] = time.perf_counter() - t0
     w_limbs = env.native.ints_to_limbs([int(v) for v in w])
     rounds = []
     for _ in range(3):
+        env.barrier()
         t0 = time.perf_counter()
         proof = prv.prove(ipk, x, w_limbs)
-        rounds.append(time.perf_counter() - t0)
+        rounds.append(env.max_over_ranks(time.perf_counter() - t0))
     t0 = time.perf_counter()
     ok = bool(plonk.Verifier(env.args.curve).verify(ivk, x, proof))
     t["verify_s"] = time.perf_counter() - t0
+    same = True
+    if sh is not None:      # every rank must hold the same proof
+        import hashlib
+        from kzg_snark_amd.sharding import all_gather_bytes
+        digest = hashlib.sha256(repr(sorted((k, tuple(int(c) for c in v)) for k, v in
+                                            list(proof["commitments"].items()) + list(proof["kzg_proofs"].items()))
+                                     ).encode()).digest()
+        same = len(set(all_gather_bytes(digest))) == 1
     del ipk, prv, idx
     torch.cuda.set_stream(prev)
     torch.cuda.empty_cache()
     out = {"metric": "PLONK prover round, 2^%d gates, %s, device-resident" % (env.args.plonk_log_n, env.args.curve),
-           "value": sorted(rounds)[1] * 1e3, "unit": "ms", "higher_is_better": False, "gates": n,
-           "rounds_ms": [v * 1e3 for v in rounds], **t, "verified": {"verifier_accepts": ok}}
-    return out, ok
+           "value": sorted(rounds)[1] * 1e3, "unit": "ms", "higher_is_better": False, "gates": n, "n_gpus": env.world,
+           "rounds_ms": [v * 1e3 for v in rounds], **t,
+           "verified": {"verifier_accepts": ok, **({"same_proof_on_every_rank": same} if sh else {})}}
+    if sh is not None:
+        out["sharding"] = ("one proof over the ranks: 3 + 1 + 3 commitments and the 2 openings dealt round-robin, "
+                           "replicated key and vector work; %d exchanges per proof (one all-gather of 97-byte records "
+                           "per round + the blinders)" % (sh.exchanges // 4))
+    return out, ok and same
 
 
 def section_dist_ntt(env):
@@ -683,6 +727,7 @@ def main(argv=None):
         ctx.ntt_device(works[0].data_ptr(), log_n, w_words, bool(i & 1) ^ True, B)
     env.barrier()
     ntt_alone = ctx.prof_read("ntt_pass")
+    mhz_ntt = ctx.prof_read("ntt_pass_shader_mhz")[0]
     # The accumulate kernel alone: in the pipelined loop it deliberately shares every SIMD with the
     # next polynomial's prep and the previous one's reduce stage, so its span there is the pipeline
     # period.  One commit at a time (flush after each) gives the kernel's own duration.
@@ -721,9 +766,10 @@ def main(argv=None):
         run_section("range_mode", section_range, env)
     if args.mode == "all" and env.collective and not args.no_dist_ntt:
         run_section("distributed_ntt", section_dist_ntt, env)
-    if args.mode == "all" and world == 1 and not args.no_plonk:
+    if args.mode == "all" and not args.no_plonk:
         run_section("plonk_round", section_plonk, env)
 
+    coll_info = env.collectives_info()      # a collective: every rank takes part
     spans = dict(spans_main)
     spans["ntt_pass"] = (ntt_alone[0] * args.steps / ntt_iters, ntt_alone[1] * args.steps // ntt_iters)
     if rank == 0:
@@ -754,6 +800,9 @@ def main(argv=None):
                        "log_n": log_n, "curve": args.curve, "batch": B, "window_bits": 20 if n >= (1 << 18) else 16,
                        "sharding": "independent polynomials per rank, replicated SRS"},
             "verified": {"last_step_commit_trapdoor": ok_headline},
+            # what the process group really was (a SCALE record then shows that RCCL saw N ranks, one GPU each)
+            "collectives": coll_info,
+            "build": env.build_info(),
             "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
             "ntt_ms": ntt_per_transform_s * 1e3,
             "kernel_ms_per_commit": {k: (v[0] / (args.steps * B)) for k, v in spans.items()},
@@ -808,6 +857,10 @@ def main(argv=None):
                                            "hbm_achieved_GBps_from_traffic": (ent["hbm_bytes"] / dur_s / 1e9)
                                            if ent.get("hbm_bytes") else None,
                                            "source": cj.get("source")}
+                    if key == "roofline_ntt" and mhz_ntt > 0:
+                        peak_at_clock = VALU_PEAK_GINSTR * mhz_ntt / SHADER_PEAK_MHZ
+                        out[key]["limiter"].update({"shader_mhz": mhz_ntt, "peak_at_measured_clock": peak_at_clock,
+                                                    "frac_at_measured_clock": ach / peak_at_clock})
                     if key == "roofline" and mhz_alone > 0:
                         # the shader clock is power-managed: the kernel reports the one it actually ran at
                         # (s_memtime / s_memrealtime, measured live), and the issue peak at THAT clock

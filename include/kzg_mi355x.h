@@ -67,7 +67,10 @@ const char* kzg_last_error(const kzg_ctx* ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work of this context.
  * NULL restores the context's own (non-blocking) stream; to run on HIP's null stream -- torch's
  * default stream -- pass hipStreamLegacy.  A context that keeps its own stream is NOT ordered with
- * work the caller enqueues elsewhere: synchronise, or bind the producer's stream. */
+ * work the caller enqueues elsewhere: synchronise, or bind the producer's stream.
+ * The handle must be a live hipStream_t of this process (or hipStreamLegacy / hipStreamPerThread): HIP has no way
+ * to validate one, so only values that cannot be runtime objects (other small integers, misaligned values) are
+ * refused with KZG_ERR_ARG; the stream must outlive its use by the context. */
 int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream);
 /* Block until everything enqueued on the context's stream has finished. */
 int kzg_ctx_synchronize(kzg_ctx* ctx);
@@ -222,8 +225,8 @@ int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4
  * Span names: "ntt_pass", "msm_partition1", "msm_partition2", "msm_order", "msm_accumulate",
  * "msm_finalize", "msm_reduce", "open_poly".  kzg_prof_read synchronises the stream and returns
  * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset.
- * One name is not a span: "msm_accumulate_shader_mhz" returns (in *total_ms) the shader clock in MHz
- * the accumulate kernel ran at since the last reset -- s_memtime over s_memrealtime ticks of its
+ * Two names are not spans: "msm_accumulate_shader_mhz" and "ntt_pass_shader_mhz" return (in *total_ms) the shader
+ * clock in MHz the accumulate / NTT kernel ran at since the last reset -- s_memtime over s_memrealtime ticks of its
  * first wave -- and *count = 1 when a launch has reported, 0 otherwise. */
 int kzg_prof_enable(kzg_ctx* ctx, int on);
 int kzg_prof_reset(kzg_ctx* ctx);

@@ -37,6 +37,47 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# What the library was built FROM decides whether it is rebuilt, not file times (a checkout, a copy to the GPU box or
+# an edited-and-reverted file all move mtimes): sha256 over every source / header of csrc and include, the compiler
+# flags and the compiler's version line, kept beside the objects in build_stamp.json.
+STAMP = os.path.join(LIBDIR, "build_stamp.json")
+LAST = {}          # what the last build() call did: {"mode": "compiled" | "reused", "compiled": [...], "linked": bool}
+
+
+def _hipcc_version():
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout
+        return next((ln for ln in out.splitlines() if "HIP version" in ln or "clang version" in ln), out[:80]).strip()
+    except (OSError, subprocess.SubprocessError):
+        return "unknown"
+
+
+def source_hash(unit=None):
+    """Hash of what `unit` (a .hip file of SOURCES; None: the whole library) is compiled from: its own text, every
+    header of csrc/ and include/, the flags and the compiler."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(_deps()):
+        base = os.path.basename(path)
+        if base.endswith(".py") or (base.endswith(".hip") and unit is not None and base != unit):
+            continue
+        h.update(base.encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    h.update(_hipcc_version().encode())
+    return h.hexdigest()
+
+
+def _read_stamp():
+    import json
+    try:
+        with open(STAMP) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 PYCONV = os.path.join(LIBDIR, "_kzg_pyconv.so")
 
 
@@ -56,16 +97,23 @@ def build_pyconv(force=False, verbose=True):
 
 
 def build(force=False, verbose=True):
+    import json
     os.makedirs(LIBDIR, exist_ok=True)
-    build_pyconv(force, verbose)
+    try:
+        build_pyconv(force, verbose)
+    except (OSError, subprocess.SubprocessError) as e:
+        # optional: _native.ints_to_limbs / limbs_to_ints fall back to int.to_bytes without the helper
+        print(f"[build] marshalling helper not built ({e}); the pure-Python conversion is used", flush=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = _deps()
+    want = source_hash()
+    units = {s: source_hash(s) for s in srcs}
+    have = {} if force else _read_stamp().get("units", {})
     objs = []
     jobs = []
     for s in srcs:
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, deps):
+        if not (have.get(s) == units[s] and os.path.exists(obj)):
             jobs.append([HIPCC, *FLAGS, "-c", os.path.join(CSRC, s), "-o", obj])
 
     def run(cmd):
@@ -75,8 +123,17 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
+    link = bool(jobs) or force or not os.path.exists(LIB) or _read_stamp().get("source_hash") != want
+    if link:
         run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", LIB])
+        with open(STAMP, "w") as f:
+            json.dump({"source_hash": want, "units": units, "flags": FLAGS, "hipcc": _hipcc_version()}, f, indent=1)
+    LAST.clear()
+    LAST.update(mode="compiled" if link else "reused", compiled=[os.path.basename(j[-3]) for j in jobs], linked=link,
+                source_hash=want)
+    if verbose:
+        print(f"[build] libkzg_mi355x.so {LAST['mode']}: source hash {want[:16]}, "
+              f"{len(jobs)} of {len(srcs)} translation units compiled", flush=True)
     return LIB
 
 

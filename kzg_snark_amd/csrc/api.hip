@@ -125,14 +125,21 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
   Ctx* c = &ctx->c;
   KZG_HIP(c, hipSetDevice(c->device));
   if (hip_stream) {
-    // Adopt only what the runtime knows as a stream of this process: any other value would reach hipEventRecord /
-    // hipStreamWaitEvent unchecked later (a host crash, gpurun_out/r02_crash.log).  hipStreamQuery looks the handle up
-    // in the runtime's stream set and resolves the hipStreamLegacy / hipStreamPerThread aliases; "not ready" is a
-    // valid stream with work in flight.
+    // What can be checked is checked before the handle is adopted.  HIP offers no validation of a stream handle:
+    // hipStreamQuery (like every other entry point) dereferences it -- a readable buffer that is no stream crashed the
+    // process on ROCm 7.2 (round 3, gpurun_out/r03_call2b_pytest.log).  So: the two documented aliases
+    // (hipStreamLegacy, hipStreamPerThread) are taken as such; any other small integer or misaligned value cannot be
+    // a runtime object and is refused (the class of gpurun_out/r02_crash.log: an alias or enum value passed where a
+    // handle belongs would reach hipEventRecord); a plausible pointer is then asked for its status, which surfaces
+    // whatever the runtime itself detects (a stream of a destroyed context, a sticky device error).
+    const uintptr_t hv = reinterpret_cast<uintptr_t>(hip_stream);
+    const bool alias = hip_stream == static_cast<void*>(hipStreamLegacy) || hip_stream == static_cast<void*>(hipStreamPerThread);
+    if (!alias && (hv < 65536 || (hv & 7)))
+      return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: not a stream handle (small integer or misaligned value)");
     const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(hip_stream));
     if (q != hipSuccess && q != hipErrorNotReady) {
       (void)hipGetLastError();
-      return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: not a HIP stream of this process", q);
+      return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: the runtime does not accept this stream", q);
     }
     if (c->own_stream && c->stream) {
       KZG_HIP(c, hipStreamSynchronize(c->stream));
@@ -491,8 +498,8 @@ int kzg_prof_enable(kzg_ctx* ctx, int on) {
   if (!ctx) return KZG_ERR_ARG;
   Ctx* c = &ctx->c;
   if (on && !c->clk_probe) {
-    KZG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->clk_probe), 16));
-    KZG_HIP(c, hipMemset(c->clk_probe, 0, 16));
+    KZG_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->clk_probe), 32));
+    KZG_HIP(c, hipMemset(c->clk_probe, 0, 32));
   }
   c->prof_on = on != 0;
   return KZG_OK;
@@ -508,7 +515,7 @@ int kzg_prof_reset(kzg_ctx* ctx) {
     sp.total_ms = 0;
     sp.count = 0;
   }
-  if (c->clk_probe) KZG_HIP(c, hipMemset(c->clk_probe, 0, 16));
+  if (c->clk_probe) KZG_HIP(c, hipMemset(c->clk_probe, 0, 32));
   return KZG_OK;
 }
 
@@ -518,10 +525,12 @@ int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* co
   KZG_HIP(c, hipDeviceSynchronize());
   *total_ms = 0;
   *count = 0;
-  if (std::string(name) == "msm_accumulate_shader_mhz") {   // not a span: the clock the accumulate kernel ran at
-    unsigned long long t[2] = {0, 0};
-    if (c->clk_probe) KZG_HIP(c, hipMemcpy(t, c->clk_probe, 16, hipMemcpyDeviceToHost));
-    if (t[1]) { *total_ms = 100.0 * (double)t[0] / (double)t[1]; *count = 1; }
+  const bool acc_clk = std::string(name) == "msm_accumulate_shader_mhz", ntt_clk = std::string(name) == "ntt_pass_shader_mhz";
+  if (acc_clk || ntt_clk) {   // not a span: the shader clock (MHz) the kernel's probing wave ran at
+    unsigned long long t[4] = {0, 0, 0, 0};
+    if (c->clk_probe) KZG_HIP(c, hipMemcpy(t, c->clk_probe, 32, hipMemcpyDeviceToHost));
+    const unsigned long long* q = t + (ntt_clk ? 2 : 0);
+    if (q[1]) { *total_ms = 100.0 * (double)q[0] / (double)q[1]; *count = 1; }
     return KZG_OK;
   }
   for (auto& sp : c->prof) {

@@ -259,6 +259,47 @@ struct Field {
     return r;
   }
 
+  // sum_{t<K} a[t]*b[t] with ONE Montgomery reduction: K*N^2 + N^2 + N multiply-adds instead of K*(2N^2 + N) --
+  // the linear combinations of KZG.open (kzg.py:148-150) and of the prover's r(X).  Weak-normal (< 2p) in and out:
+  // (K*4p^2 + m*p)/R < 2p needs 4K*p <= R.  A column takes the a*b products of one term after the other and is cut
+  // (low L bits stay in the chain, the rest joins the outgoing carry) whenever the next group would pass its capacity.
+  template <int K>
+  static KZG_HD E dot(const E* a, const E* b) {
+    static_assert(K >= 1 && F::BITS + 2 + (K > 8 ? 4 : K > 4 ? 3 : K > 2 ? 2 : K > 1 ? 1 : 0) <= L * N, "dot needs 4K*p <= R");
+    uint32_t m[N];
+    E r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * N - 1; ++k) {
+      const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+      const int nab = hi - lo + 1;                       // a*b products of ONE term in this column
+      const int nmp = k < N ? k + 1 : nab;
+      uint64_t upper = 0;
+      int used = 1;                                      // the incoming carry (< 2^(64-L)) counts as one product
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        if (used + nab > FIT) { upper += acc >> L; acc &= (uint64_t)MASK; used = 1; }
+#pragma unroll
+        for (int i = lo; i <= hi; ++i) acc = mad_wide(a[t].l[i], b[t].l[k - i], acc);
+        used += nab;
+      }
+      if (used + nmp > FIT) { upper += acc >> L; acc &= (uint64_t)MASK; used = 1; }
+#pragma unroll
+      for (int i = lo; i <= hi; ++i)
+        if (i < k || k >= N) acc = mad_wide(m[i], F::P[k - i], acc);
+      if (k < N) {
+        m[k] = ((uint32_t)acc * F::N0) & MASK;
+        acc = mad_wide(m[k], F::P[0], acc);
+      } else {
+        r.l[k - N] = (uint32_t)acc & MASK;
+      }
+      acc >>= L;
+      acc += upper;
+    }
+    r.l[N - 1] = (uint32_t)acc;
+    return r;
+  }
+
   // a + b, weak-normal in and out
   static KZG_HD E add(const E& a, const E& b) {
     E s, t;

@@ -64,7 +64,7 @@ struct Ctx {
   void* msm_work = nullptr;               // MsmWork (msm.hip)
   bool prof_on = false;
   std::vector<ProfSpan> prof;
-  unsigned long long* clk_probe = nullptr;   // [2] shader-clock / 100 MHz ticks spent in msm_accumulate (profiling only)
+  unsigned long long* clk_probe = nullptr;   // [4] shader-clock / 100 MHz ticks of one wave of msm_accumulate ([0..1]) and of ntt_pass ([2..3]); profiling only
   std::vector<hipStream_t> aux_streams;   // commit pipeline
   std::vector<hipEvent_t> aux_events;
 };

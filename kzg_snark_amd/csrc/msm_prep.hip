@@ -13,10 +13,14 @@
 //     count1      digits of a chunk -> LDS histogram over NBIN bins (high bucket bits)
 //     row_scan    per bin: exclusive prefix over chunks;  bins: bin starts, chunk list for step 2
 //     scatter1    digits again -> 8-byte entries (low bucket bits | table index, sign) into the bin
-//   partition 2   (one segment per bin, chunks of CH2 entries; a skewed bin gets many chunks)
-//     count2      LDS histogram over the BPB buckets of the bin
-//     scan2       per bin: prefix over its chunks and over buckets -> bstart[] (bucket bounds)
-//     scatter2    table indices to their bucket
+//   partition 2   (one segment per bin)
+//     binsort     a bin of <= STAGE_CAP entries (every bin, with uniform scalars) is sorted by ONE workgroup: LDS
+//                 histogram over its BPB buckets -> bstart[]; ranks by LDS atomics; the table indices are placed in
+//                 an LDS stage of the bin's size and leave as one contiguous, fully coalesced run -- the HBM write
+//                 is the payload (round 2 scattered 4-byte elements to 1024 open runs per workgroup, which the L2
+//                 handed on as partial lines: WRITE_SIZE 7.4x the payload);
+//     count2 / scan2 / scatter2   the chunked form of the same (chunks of CH2 entries, histogram per chunk, prefix
+//                 over chunks and buckets, scattered stores) for a bin that outgrows the stage: skewed scalars only
 //   order         buckets by length class (255 - min(len, 255): longest first), the same
 //                 count / row_scan / scatter scheme with 256 classes; slices of <= SEG entries
 //                 per bucket and their exclusive scan (slice_off, two-level, same kernels); arms
@@ -37,9 +41,10 @@ template <int WB>
 struct PW {
   static constexpr int NWIN = (256 + WB - 1) / WB;
   static constexpr uint32_t NB = 1u << (WB - 1);
-  static constexpr int LOB = WB >= 20 ? 10 : 9;           // low bucket bits: buckets per bin
+  static constexpr int LOB = 8;                           // low bucket bits: buckets per bin
   static constexpr uint32_t BPB = 1u << LOB;
-  static constexpr uint32_t NBIN = NB >> LOB;             // 512 (c = 20) / 64 (c = 16)
+  static constexpr uint32_t NBIN = NB >> LOB;             // 2048 (c = 20) / 128 (c = 16): a uniform 2^20-scalar
+                                                          // commit puts 6.6 K entries into each bin
 };
 constexpr uint32_t TPB = 256;     // threads per workgroup, every kernel here
 #ifndef KZG_PREP_PRIO
@@ -52,7 +57,11 @@ constexpr uint32_t CH1 = KZG_PREP_CH1;    // scalars per partition-1 chunk
 #ifndef KZG_PREP_CH2
 #define KZG_PREP_CH2 8192
 #endif
-constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk
+constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk (bins beyond the stage)
+#ifndef KZG_PREP_STAGE_CAP
+#define KZG_PREP_STAGE_CAP 7168
+#endif
+constexpr uint32_t STAGE_CAP = KZG_PREP_STAGE_CAP;   // entries a bin may have to be sorted in LDS: 28 KiB of table indices
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
 constexpr uint32_t NCLS = 256;    // length classes
 
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(TPB) void prep_bins_kernel(const uint32_t* bin_tota
   for (uint32_t base = 0; base < P::NBIN; base += TPB) {
     const uint32_t s = base + threadIdx.x;
     const uint32_t size = s < P::NBIN ? bin_total[s] : 0u;
-    const uint32_t nc = (size + CH2 - 1) / CH2;
+    const uint32_t nc = size > STAGE_CAP ? (size + CH2 - 1) / CH2 : 0u;    // a bin that fits the stage needs no chunks
     const uint32_t size_incl = block_inclusive_scan(size, sh);
     const uint32_t size_tot = sh[TPB - 1];
     __syncthreads();
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(TPB) void prep_scan2_kernel(uint32_t* hist2, const 
   __shared__ uint32_t sh[TPB];
   const uint32_t s = blockIdx.x;
   const uint32_t c0 = chunk_base[s], c1 = chunk_base[s + 1];
+  if (c0 == c1) return;                                   // sorted by prep_binsort_kernel (or empty)
   for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB) {
     uint32_t run = 0;
     for (uint32_t c = c0; c < c1; ++c) {
@@ -274,6 +284,58 @@ __global__ __launch_bounds__(TPB) void prep_scatter2_kernel(const uint64_t* ent,
     const uint32_t pos = atomicAdd(&cur[(uint32_t)(v >> 32)], 1u);
     vals[pos] = (uint32_t)v;
   }
+}
+
+// One workgroup sorts a whole bin (<= STAGE_CAP entries) through registers and LDS: every thread keeps its <= EPT
+// entries in registers, LDS histogram over the bin's buckets, exclusive scan -> bstart[], ranks by LDS atomics, table
+// indices staged in LDS at their final offset inside the bin, then one contiguous copy to vals[bin_start ..).
+// Reads every entry once and writes each output byte once, in full lines.
+template <int WB>
+__global__ __launch_bounds__(TPB) void prep_binsort_kernel(const uint64_t* ent, const uint32_t* bin_start,
+                                                           uint32_t* bstart, uint32_t* vals) {
+  using P = PW<WB>;
+  constexpr uint32_t PER = P::BPB / TPB;
+  constexpr uint32_t EPT = STAGE_CAP / TPB;               // entries per thread
+  static_assert(PER >= 1, "one thread owns PER consecutive buckets in the scan");
+  static_assert(STAGE_CAP % TPB == 0, "the stage is a whole number of entries per thread");
+  side_priority();
+  __shared__ uint32_t cur[P::BPB];
+  __shared__ uint32_t sh[TPB];
+  __shared__ uint32_t stage[STAGE_CAP];
+  const uint32_t s = blockIdx.x;
+  const uint32_t e0 = bin_start[s], e1 = bin_start[s + 1];
+  const uint32_t size = e1 - e0;
+  if (size > STAGE_CAP) return;                           // the chunked kernels take this bin
+  for (uint32_t b = threadIdx.x; b < P::BPB; b += TPB) cur[b] = 0;
+  uint64_t mine_e[EPT];
+#pragma unroll
+  for (uint32_t q = 0; q < EPT; ++q) {
+    const uint32_t e = e0 + q * TPB + threadIdx.x;
+    mine_e[q] = e < e1 ? ent[e] : ~0ull;                  // ~0: no entry (a real key is < BPB)
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t q = 0; q < EPT; ++q)
+    if ((uint32_t)(mine_e[q] >> 32) < P::BPB) atomicAdd(&cur[(uint32_t)(mine_e[q] >> 32)], 1u);
+  __syncthreads();
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) mine += cur[threadIdx.x * PER + q];
+  const uint32_t incl = block_inclusive_scan(mine, sh);
+  uint32_t run = incl - mine;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; ++q) {
+    const uint32_t cnt = cur[threadIdx.x * PER + q];
+    bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = e0 + run;
+    cur[threadIdx.x * PER + q] = run;                     // becomes the running rank inside the bin
+    run += cnt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t q = 0; q < EPT; ++q)
+    if ((uint32_t)(mine_e[q] >> 32) < P::BPB) stage[atomicAdd(&cur[(uint32_t)(mine_e[q] >> 32)], 1u)] = (uint32_t)mine_e[q];
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < size; i += TPB) vals[e0 + i] = stage[i];
 }
 
 // ---- buckets in length order ----------------------------------------------------------
@@ -439,6 +501,7 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
   KZG_HIP(c, hipGetLastError());
   {
     ProfScope ps(c, "msm_partition2", sp);
+    hipLaunchKernelGGL(prep_binsort_kernel<WB>, dim3(P::NBIN), dim3(TPB), 0, sp, ent, bin_start, bstart, vals);
     hipLaunchKernelGGL(prep_count2_kernel<WB>, dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
                        seg_of_chunk, nchunk2, hist2);
     hipLaunchKernelGGL(prep_scan2_kernel<WB>, dim3(P::NBIN), dim3(TPB), 0, sp, hist2, bin_start, chunk_base, bstart);

@@ -72,6 +72,7 @@ struct NttPassArgs {
   uint32_t ld_shift, st_shift;
   uint64_t batch_stride;   // elements between transforms of a batch (blockIdx.y)
   uint32_t pair_tiles;     // g > 0: remap blockIdx so that each group of 2^g adjacent tiles lands on one XCD
+  unsigned long long* clk; // profiling only (null otherwise): [0] += shader-clock ticks, [1] += 100 MHz ticks of one wave
 };
 
 // LDS word address of element `pos` of line `line`.  Elements are 9 words; one
@@ -170,6 +171,10 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
   // (alone it changes nothing; in the commit pipeline at B = 4: 416-417 vs 409-410 commits/s on one box, r02c)
   __builtin_amdgcn_s_setprio(KZG_NTT_PRIO);
   const uint32_t T = blockDim.x, tid = threadIdx.x;
+  // profiling only: wave 0 of workgroup (0, 0) reports the shader clock it ran at -- s_memtime (shader clock) against
+  // s_memrealtime (100 MHz) over its lifetime, like the accumulate kernel does (the clock is power-managed)
+  const bool probe = a.clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
+  const long long pc0 = probe ? clock64() : 0, pw0 = probe ? wall_clock64() : 0;
   const uint32_t k = a.k, logC = a.logC;
   const uint32_t LEN = 1u << k, C = 1u << logC, TILE = LEN << logC;
   // Adjacent tiles share 128-byte lines when a tile holds fewer than 4 columns; workgroups b and
@@ -287,6 +292,10 @@ __global__ __launch_bounds__(1024) void ntt_pass_kernel(NttPassArgs a) {
     g[0] = make_uint4(w[0], w[1], w[2], w[3]);
     g[1] = make_uint4(w[4], w[5], w[6], w[7]);
   }
+  if (probe && tid == 0) {
+    atomicAdd(a.clk, (unsigned long long)(clock64() - pc0));
+    atomicAdd(a.clk + 1, (unsigned long long)(wall_clock64() - pw0));
+  }
 }
 
 // one launch: picks the instantiation for the pass's layout and epilogue
@@ -309,7 +318,9 @@ int launch_pass(Ctx* c, const NttPassArgs& a, uint64_t tiles, uint32_t batch, ui
     c->ntt_lds_attr_set |= (1u << slot);
   }
   ProfScope ps(c, "ntt_pass");
-  hipLaunchKernelGGL(kern, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, a);
+  NttPassArgs launch_args = a;
+  launch_args.clk = (c->prof_on && c->clk_probe) ? c->clk_probe + 2 : nullptr;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)tiles, batch), dim3(threads), lds_bytes, c->stream, launch_args);
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
 }

@@ -76,6 +76,23 @@ __device__ __forceinline__ void store_limbs(uint32_t* p, const Fe<F>& v) {
   for (int j = 0; j < F::N; ++j) p[j] = v.l[j];
 }
 
+// sum over up to DOT_G terms c_g * x_g with ONE Montgomery reduction (Field::dot): 81 multiply-adds per term plus 74
+// for the group, against 155 per term for separate products -- the combination kernels are bound by exactly these
+// multiply-adds (rocprofv3, profiles/r03_open_pmc.csv: 31 M VALU wave-instructions per 2^20 x 6 combination before).
+constexpr uint32_t DOT_G = 6;
+template <class F>
+__device__ __forceinline__ Fe<F> dot_upto(uint32_t cnt, const Fe<F>* c, const Fe<F>* x) {
+  using Fd = Field<F>;
+  switch (cnt) {                                             // uniform over the launch
+    case 1: return Fd::template dot<1>(c, x);
+    case 2: return Fd::template dot<2>(c, x);
+    case 3: return Fd::template dot<3>(c, x);
+    case 4: return Fd::template dot<4>(c, x);
+    case 5: return Fd::template dot<5>(c, x);
+    default: return Fd::template dot<6>(c, x);
+  }
+}
+
 // out[t] = sum_i xipow[i] * p_i[t]   (xipow in Montgomery form => result in standard form)
 template <class F>
 __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
@@ -84,11 +101,18 @@ __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   Fe<F> acc = Fd::zero();
-  for (uint32_t i = 0; i < a.k; ++i) {
-    if (t < a.lens[i]) {
-      const Fe<F> c = load_words<F>(a.polys + (a.stride * i + t) * 8);
-      acc = Fd::add(acc, Fd::mul(c, load_limbs<F>(a.xipow + i * F::N)));
+  for (uint32_t i0 = 0; i0 < a.k; i0 += DOT_G) {
+    const uint32_t cnt = min(DOT_G, a.k - i0);
+    Fe<F> c[DOT_G], x[DOT_G];
+#pragma unroll
+    for (uint32_t g = 0; g < DOT_G; ++g) {
+      const uint32_t i = i0 + g;
+      const bool on = g < cnt && t < a.lens[i];               // shorter polynomials read as zero-padded
+      c[g] = on ? load_words<F>(a.polys + (a.stride * i + t) * 8) : Fd::zero();
+      x[g] = load_limbs<F>(a.xipow + (g < cnt ? i : i0) * F::N);
     }
+    const Fe<F> part = dot_upto<F>(cnt, c, x);
+    acc = i0 ? Fd::add(acc, part) : part;
   }
   store_words<F>(out + (size_t)t * 8, acc);
 }
@@ -388,7 +412,8 @@ struct ScalarLincombArgs {
   uint32_t scal[MAXK * FR_LIMBS];   // s_j, Montgomery form
   uint32_t k;
 };
-// out[i] = sum_j s_j * p_j[i]  (s_j in Montgomery form; p_j shorter than n count as zero-padded)
+// out[i] = sum_j s_j * p_j[i]  (s_j in Montgomery form; p_j shorter than n count as zero-padded); groups of DOT_G
+// terms share one Montgomery reduction
 template <class F>
 __global__ void vec_lincomb_kernel(ScalarLincombArgs a, uint32_t* out, uint32_t n) {
   using Fd = Field<F>;
@@ -396,8 +421,19 @@ __global__ void vec_lincomb_kernel(ScalarLincombArgs a, uint32_t* out, uint32_t 
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   Fe<F> acc = Fd::zero();
-  for (uint32_t j = 0; j < a.k; ++j)
-    if (t < a.len[j]) acc = Fd::add(acc, Fd::mul(load_words<F>(a.ptr[j] + (size_t)t * 8), load_limbs<F>(a.scal + j * F::N)));
+  for (uint32_t j0 = 0; j0 < a.k; j0 += DOT_G) {
+    const uint32_t cnt = min(DOT_G, a.k - j0);
+    Fe<F> c[DOT_G], x[DOT_G];
+#pragma unroll
+    for (uint32_t g = 0; g < DOT_G; ++g) {
+      const uint32_t j = j0 + g;
+      const bool on = g < cnt && t < a.len[j];
+      c[g] = on ? load_words<F>(a.ptr[j] + (size_t)t * 8) : Fd::zero();
+      x[g] = load_limbs<F>(a.scal + (g < cnt ? j : j0) * F::N);
+    }
+    const Fe<F> part = dot_upto<F>(cnt, c, x);
+    acc = j0 ? Fd::add(acc, part) : part;
+  }
   store_words<F>(out + (size_t)t * 8, acc);
 }
 

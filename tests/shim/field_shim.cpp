@@ -53,6 +53,20 @@ static void op(int which, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     }
     case 18: R = Fd::mul(Fd::template sub_carry_cneg<2>(Fd::mul(A, Fd::one()), true, Fd::mul(B, Fd::one())), Fd::one()); break;    // -a - b
     case 19: R = Fd::mul(Fd::template sub_carry_cneg<2>(Fd::mul(A, Fd::one()), false, Fd::mul(B, Fd::one())), Fd::one()); break;   //  a - b
+    case 20: {  // dot<6>: a*b + (a+b)(a-b) + b*b + a*a + (a-b)*b + (a+b)*a, weak-normal operands, one reduction
+      const typename Fd::E x[6] = {A, Fd::add(A, B), B, A, Fd::sub(A, B), Fd::add(A, B)};
+      const typename Fd::E y[6] = {B, Fd::sub(A, B), B, A, B, A};
+      R = Fd::template dot<6>(x, y);
+      break;
+    }
+    case 21: {  // dot<1> == mul, dot<2> == mul2, dot<3>
+      const typename Fd::E x[3] = {A, Fd::add(A, B), Fd::neg_weak(B)};
+      const typename Fd::E y[3] = {B, Fd::sub(B, A), A};
+      R = Fd::add(Fd::template dot<3>(x, y), Fd::add(Fd::template dot<1>(x, y), Fd::template dot<2>(x, y)));
+      if (!Fd::eq(Fd::template dot<1>(x, y), Fd::mul(A, B)) || !Fd::eq(Fd::template dot<2>(x, y), Fd::mul2(x[0], y[0], x[1], y[1])))
+        R = Fd::zero();
+      break;
+    }
     default: R = Fd::zero();
   }
   Fd::to_words(Fd::from_mont(R), out);

@@ -42,7 +42,10 @@ def test_field_ops(shim, fid, p, nw):
            (12, lambda a, b: a % p), (13, lambda a, b: 1 if (a - b) % p == 0 else 0),
            (14, lambda a, b: (a + 2 * b) * (a - b) % p), (15, lambda a, b: (2 * a - b) ** 2 % p),
            (16, lambda a, b: ((a - b) * (2 * a - b) - a * b) % p), (17, lambda a, b: (16 * a + 15 * b) % p),
-           (18, lambda a, b: (-a - b) % p), (19, lambda a, b: (a - b) % p)]
+           (18, lambda a, b: (-a - b) % p), (19, lambda a, b: (a - b) % p),
+           (20, lambda a, b: (a * b + (a + b) * (a - b) + b * b + a * a + (a - b) * b + (a + b) * a) % p),
+           # dot<3> + dot<1> + dot<2> over (a*b, (a+b)(b-a), -b*a)
+           (21, lambda a, b: ((a * b + (a + b) * (b - a) - b * a) + a * b + (a * b + (a + b) * (b - a))) % p)]
     for _ in range(1500):
         a = rng.choice([0, 1, 2, p - 1, p - 2, rng.randrange(p), rng.randrange(p), 1 << (p.bit_length() - 1)])
         b = rng.choice([0, 1, p - 1, rng.randrange(p), rng.randrange(p)])

@@ -55,4 +55,9 @@ def test_prep_kernels_are_small(kernels):
     prep = [k for k in kernels if k[0].startswith("prep_") or "prep_" in k[0]]
     assert len(prep) >= 10
     for name, vgpr, lds, scratch in prep:
-        assert vgpr <= 64 and lds <= 6 * 1024 and scratch == 0, name
+        # the bin sort stages a whole bin (28 KiB of table indices): ONE of its workgroups fits the 46 KiB the four
+        # accumulate workgroups of a CU leave; the partition-1 histograms hold 2048 bins (8 KiB)
+        # (and its threads keep the bin's entries in registers between the two passes: 2 x 28 VGPRs; two accumulate
+        # waves leave 512 - 2 x 153 registers of a SIMD, so such a wave still fits twice)
+        cap, regs = (31 * 1024, 96) if "binsort" in name else (9 * 1024, 64)
+        assert vgpr <= regs and lds <= cap and scratch == 0, name

@@ -224,3 +224,116 @@ def test_range_partition():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
     assert round_robin(5, 2) == [0, 1, 0, 1, 0]
+
+
+def _golden(name):
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+
+
+def _check_frozen_proof(proof, gp):
+    """proof dict == tests/golden/plonk_proof_n16.json, bit for bit"""
+    want = gp["proof"]
+    for k, v in want["commitments"].items():
+        assert tuple(int(c) for c in proof["commitments"][k]) == (int(v[0], 16), int(v[1], 16), v[2]), k
+    for k, v in want["evaluations"].items():
+        assert int(proof["evaluations"][k]) == int(v, 16), k
+    for k, v in want["kzg_proofs"].items():
+        assert tuple(int(c) for c in proof["kzg_proofs"][k]) == (int(v[0], 16), int(v[1], 16), v[2]), k
+
+
+def _plonk_worker(rank, world, port, q, device):
+    """One rank of a PLONK proof dealt over `world` ranks (sharding.ProofSharding; BASELINE config 5 on several
+    GPUs).  device=False: host prover, the oracle standing in for the engine's commit / open / INTT (CPU);
+    device=True: the device prover on cuda:0 (every rank on the test box's one GPU)."""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        import test_plonk as TP
+        from kzg_snark_amd import plonk
+        from kzg_snark_amd.sharding import ProofSharding
+        gp = _golden("plonk_proof_n16.json")
+        circuit = TP.fixture_instance()
+        curve, tau = gp["curve"], int(gp["tau"], 16)
+        blinders = [int(v, 16) for v in gp["blinders"]]
+        if not device:
+            from kzg_snark_amd.field import PolynomialRing
+            plonk.fft_ff_interpolation = lambda values, g, F: PolynomialRing(F, "X")(
+                O.fft_ff_interpolation([int(v) for v in values], int(g), F.p))
+            sh = ProofSharding()
+            idx, prv = plonk.Indexer(curve), plonk.Prover(curve, sharding=sh)
+            idx.kzg = prv.kzg = TP.oracle_backed(curve)
+            ipk, ivk = idx.preprocess(*circuit[:6], tau=tau)
+            # only rank 0's blinders count: the others pass different ones and must end with the same proof
+            mine = blinders if rank == 0 else [b + 1 + rank for b in blinders]
+            proof = prv.prove(ipk, circuit[6], circuit[7], blinders=mine)
+            _check_frozen_proof(proof, gp)
+            assert sh.exchanges == 1 + 3 + 1, sh.exchanges        # blinders, three rounds of commitments, the openings
+        else:
+            from kzg_snark_amd import plonk_device
+            idx = plonk_device.DeviceIndexer(curve)
+            ipk, ivk = idx.preprocess(*circuit[:6], tau=tau)
+            for deal in (False, True):
+                sh = ProofSharding(deal_transforms=deal)
+                prv = plonk_device.DeviceProver(curve, alg=idx.alg, sharding=sh)
+                mine = blinders if rank == 0 else [b + 1 + rank for b in blinders]
+                proof = prv.prove(ipk, circuit[6], circuit[7], blinders=mine)
+                _check_frozen_proof(proof, gp)
+                assert sh.exchanges == 5 + (8 if deal else 0), (deal, sh.exchanges)
+                assert plonk.Verifier(curve).verify(ivk, circuit[6], proof)
+            # a larger synthetic circuit: all ranks end with the same proof, and the verifier accepts it
+            from kzg_snark_amd.field import GF
+            F = GF(O.BLS12_381.r)
+            big = plonk.synthetic_circuit(1 << 12, F, seed=12)
+            idx2 = plonk_device.DeviceIndexer("bls12_381")
+            ipk2, ivk2 = idx2.preprocess(*big[:6], tau=0x1234567)
+            sh = ProofSharding()
+            prv2 = plonk_device.DeviceProver("bls12_381", alg=idx2.alg, sharding=sh)
+            proof2 = prv2.prove(ipk2, big[6], big[7])                          # random blinders: rank 0's are shared
+            assert plonk.Verifier("bls12_381").verify(ivk2, big[6], proof2)
+            import hashlib
+            digest = hashlib.sha256(repr(sorted((k, tuple(int(c) for c in v)) for k, v in
+                                                list(proof2["commitments"].items())
+                                                + list(proof2["kzg_proofs"].items()))).encode()).digest()
+            from kzg_snark_amd.sharding import all_gather_bytes
+            assert len(set(all_gather_bytes(digest))) == 1, "ranks ended with different proofs"
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_plonk_ranks(world, device, timeout):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plonk_worker, args=(r, world, port, q, device)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_plonk_proof_dealt_over_ranks_is_the_frozen_proof(world):
+    """BASELINE config 5 across ranks (plonk/prover.py:89,113,136,184-185 dealt by sharding.ProofSharding): the
+    reference's 16-gate instance proved by 2 and by 3 ranks -- commitments of a round round-robin, one opening per
+    rank, blinders from rank 0 -- reproduces tests/golden/plonk_proof_n16.json bit for bit on every rank."""
+    _run_plonk_ranks(world, device=False, timeout=300)
+
+
+@pytest.mark.gpu
+def test_device_prover_dealt_over_two_ranks_on_one_gpu():
+    """The same with the device prover (kzg_snark_amd/plonk_device.py), two ranks sharing the test box's GPU over
+    gloo: the frozen 16-gate proof bit for bit with replicated and with dealt transforms, and a 2^12-gate
+    BLS12-381 proof that every rank ends with identically and the host verifier accepts."""
+    _run_plonk_ranks(2, device=True, timeout=600)

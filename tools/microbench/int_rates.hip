@@ -186,6 +186,23 @@ SIMPLE_OP(OpAddCoOnly, "v_add_co_u32(asm)", "v_add_co_u32 %0, vcc, %0, %1")
 SIMPLE_OP(OpSubrevCo, "v_subb_co_u32(asm)", "v_subb_co_u32 %0, vcc, %0, %1, vcc")
 SIMPLE_OP(OpPerm, "v_perm_b32(asm)", "v_perm_b32 %0, %0, %1, %2")
 SIMPLE_OP(OpDot4, "v_dot4_u32_u8(asm)", "v_dot4_u32_u8 %0, %0, %1, %2")
+#define WIDE_OP(NAME, TEXT, ASM)                                                         \
+  struct NAME {                                                                          \
+    static constexpr const char* name = TEXT;                                            \
+    __device__ static void run(uint64_t (&a)[CH], uint32_t x, uint32_t y) {              \
+      _Pragma("unroll") for (int c = 0; c < CH; ++c) asm volatile(ASM : "+v"(a[c]) : "v"(x), "v"(y)); \
+    }                                                                                    \
+  };
+WIDE_OP(OpLshr64, "v_lshrrev_b64(asm)", "v_lshrrev_b64 %0, 29, %0")
+WIDE_OP(OpLshl64, "v_lshlrev_b64(asm)", "v_lshlrev_b64 %0, 3, %0")
+WIDE_OP(OpAshr64, "v_ashrrev_i64(asm)", "v_ashrrev_i64 %0, 29, %0")
+WIDE_OP(OpMov64, "v_mov_b64(asm)", "v_mov_b64 %0, %0")
+SIMPLE_OP(OpLshlV, "v_lshlrev_b32 by vgpr(asm)", "v_lshlrev_b32 %0, %1, %0")
+SIMPLE_OP(OpLshrV, "v_lshrrev_b32 by vgpr(asm)", "v_lshrrev_b32 %0, %1, %0")
+SIMPLE_OP(OpLshl16, "v_lshlrev_b32 by 16(asm)", "v_lshlrev_b32 %0, 16, %0")
+SIMPLE_OP(OpSubrev, "v_subrev_u32(asm)", "v_subrev_u32 %0, %0, %1")
+SIMPLE_OP(OpAddDpp, "v_add_u32 dpp quad_perm(asm)", "v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+SIMPLE_OP(OpMovDpp, "v_mov_b32 dpp row_shr:1(asm)", "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
 SIMPLE_OP(OpMadU16, "v_mad_u32_u16(asm)", "v_mad_u32_u16 %0, %0, %1, %2")
 
 template <class Op>
@@ -250,6 +267,8 @@ int main() {
   RUN(OpAshr) RUN(OpMov) RUN(OpBfe) RUN(OpAlignbit) RUN(OpAndOr) RUN(OpLshlAdd32) RUN(OpAddLshl) RUN(OpLshlOr)
   RUN(OpCndmask) RUN(OpMulU24) RUN(OpMaxU32) RUN(OpPkAddU16) RUN(OpAddCoOnly) RUN(OpSubrevCo) RUN(OpPerm) RUN(OpDot4)
   RUN(OpMadU16) RUN(OpAdd3) RUN(OpMad64Pure)
+  RUN(OpLshr64) RUN(OpLshl64) RUN(OpAshr64) RUN(OpMov64) RUN(OpLshlV) RUN(OpLshrV) RUN(OpLshl16) RUN(OpSubrev)
+  RUN(OpAddDpp) RUN(OpMovDpp)
   printf("--- 4 waves/SIMD ---\n");
   blocks = 256 * 4;
   RUN(OpFma32) RUN(OpAddU32) RUN(OpAndB32) RUN(OpLshr) RUN(OpAdd3) RUN(OpMad64Pure)

@@ -43,7 +43,10 @@ def stats(path, out_name):
         for r in rows:
             f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
                     f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
-    return {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+    out = collections.defaultdict(list)      # a kernel template may appear as several rows (one per instantiation)
+    for r in rows:
+        out[short(r["Name"])].append((float(r["AverageNs"]), int(r["Calls"])))
+    return out
 
 
 avg_ns = stats(one("trace/**/*kernel_stats.csv"), f"{tag}_kernel_stats.csv")
@@ -85,11 +88,16 @@ out = {
               "MI355X_MICROARCH.md; bench.py --mode batch --steps 3)",
     "msm_accumulate_kernel": {"hbm_bytes": traffic("msm_accumulate_kernel"),
                               "valu_wave_instructions": valu("msm_accumulate_kernel"),
-                              "avg_ns_pipelined_under_profiler": avg_ns.get("msm_accumulate_kernel")},
+                              "avg_ns_pipelined_under_profiler": (avg_ns.get("msm_accumulate_kernel") or [(None, 0)])[0][0]},
     "ntt_pass_kernel_per_transform": {"hbm_bytes": 2 * traffic("ntt_pass_kernel") / batch,
                                       "valu_wave_instructions": (2 * valu("ntt_pass_kernel") / batch) if valu("ntt_pass_kernel") else None,
                                       "ntt_batch_per_launch": batch,
-                                      "avg_ns_per_launch_alone_under_profiler": ntt_alone_ns.get("ntt_pass_kernel")},
+                                      # the two passes of a transform are two instantiations (twist / reduce epilogue):
+                                      # one launch of each per batch of transforms
+                                      "avg_ns_per_transform_alone_under_profiler":
+                                          (sum(a for a, _ in ntt_alone_ns.get("ntt_pass_kernel", [])) / batch) or None,
+                                      "avg_ns_per_launch_alone_under_profiler":
+                                          [a for a, _ in ntt_alone_ns.get("ntt_pass_kernel", [])]},
 }
 json.dump(out, open(os.path.join(dst, "counters.json"), "w"), indent=1)
 shutil.copy(os.path.join(src, "trace_bench.log"), os.path.join(dst, f"{tag}_bench_under_rocprof.log"))

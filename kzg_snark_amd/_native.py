@@ -414,7 +414,25 @@ class Srs:
 _contexts = {}
 
 
-def get_context(curve_type, device=0):
+def default_device():
+    """The GPU the facade uses when none is named: KZG_MI355X_DEVICE, else torch's current device when this process
+    has already initialised torch.cuda (one process per GPU: the launcher's torch.cuda.set_device(local_rank)), else 0."""
+    import sys
+    env = os.environ.get("KZG_MI355X_DEVICE")
+    if env:
+        return int(env)
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                return int(torch.cuda.current_device())
+        except Exception:    # noqa: BLE001 -- a torch without a usable GPU runtime: the engine will say so itself
+            pass
+    return 0
+
+
+def get_context(curve_type, device=None):
+    device = default_device() if device is None else int(device)
     key = (curve_type, device)
     if key not in _contexts:
         _contexts[key] = Context(curve_type, device)

@@ -61,6 +61,10 @@ constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk (bins
 #ifndef KZG_PREP_STAGE_CAP
 #define KZG_PREP_STAGE_CAP 7168
 #endif
+#ifndef KZG_PREP_SWEEPS
+#define KZG_PREP_SWEEPS 1
+#endif
+constexpr uint32_t SWEEPS = KZG_PREP_SWEEPS;         // bin ranges the partition-1 scatter walks its chunk for (1: all at once)
 constexpr uint32_t STAGE_CAP = KZG_PREP_STAGE_CAP;   // entries a bin may have to be sorted in LDS: 28 KiB of table indices
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
 constexpr uint32_t NCLS = 256;    // length classes
@@ -187,13 +191,20 @@ __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scal
   for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + chunk];
   __syncthreads();
   const uint32_t base = chunk * CH1;
-  for (uint32_t it = 0; it < CH1 / TPB; ++it) {
-    const uint32_t i = base + it * TPB + threadIdx.x;
-    if (i < n)
-      for_each_digit<WB>(scalars, i, [&](uint32_t j, uint32_t key, uint32_t neg) {
-        const uint32_t pos = atomicAdd(&cur[key >> P::LOB], 1u);
-        ent[pos] = ((uint64_t)(key & (P::BPB - 1)) << 32) | (uint64_t)((j * srs_n + i) | (neg << 31));
-      });
+  // SWEEPS > 1 (experiment switch): the chunk is walked once per range of NBIN / SWEEPS bins, so that a workgroup has
+  // fewer runs open at a time (its scalars come from L2 after the first walk; the digits are extracted again)
+  for (uint32_t sweep = 0; sweep < SWEEPS; ++sweep) {
+    const uint32_t b_lo = sweep * (P::NBIN / SWEEPS), b_hi = b_lo + P::NBIN / SWEEPS;
+    for (uint32_t it = 0; it < CH1 / TPB; ++it) {
+      const uint32_t i = base + it * TPB + threadIdx.x;
+      if (i < n)
+        for_each_digit<WB>(scalars, i, [&](uint32_t j, uint32_t key, uint32_t neg) {
+          const uint32_t bin = key >> P::LOB;
+          if (SWEEPS > 1 && (bin < b_lo || bin >= b_hi)) return;
+          const uint32_t pos = atomicAdd(&cur[bin], 1u);
+          ent[pos] = ((uint64_t)(key & (P::BPB - 1)) << 32) | (uint64_t)((j * srs_n + i) | (neg << 31));
+        });
+    }
   }
 }
 

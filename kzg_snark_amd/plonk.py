@@ -143,7 +143,7 @@ class Prover:
         b = [Fq.random_element() for _ in range(11)] if blinders is None else [Fq(v) for v in blinders]
         assert len(b) == 11
         sh = self.sharding
-        if sh is not None and sh.world > 1:
+        if sh is not None and sh.active:
             b = [Fq(v) for v in sh.shared_scalars([int(v) for v in b])]              # drawn once, by rank 0
 
         def commit(polys):                                                          # plonk/prover.py:89,113,136

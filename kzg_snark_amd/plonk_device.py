@@ -27,9 +27,16 @@ from .transcript import Transcript
 class DeviceAlgebra:
     """Thin helper around the C ABI's kzg_fr_* and NTT entry points for torch tensors."""
 
-    def __init__(self, curve_type, device="cuda:0"):
-        self.ctx = _native.get_context(curve_type)
-        self.dev = torch.device(device)
+    def __init__(self, curve_type, device=None):
+        """`device`: "cuda:N" / N / None = the process's GPU (_native.default_device(): one process per GPU)."""
+        if device is None:
+            idx = _native.default_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = torch.device(device).index or 0
+        self.ctx = _native.get_context(curve_type, idx)
+        self.dev = torch.device("cuda", idx)
         self.stream = torch.cuda.Stream(device=self.dev)
         torch.cuda.set_stream(self.stream)        # every torch op of this thread shares the library's stream
         self.ctx.set_stream(self.stream.cuda_stream)
@@ -136,9 +143,9 @@ class DeviceAlgebra:
 
 
 class DeviceIndexer:
-    def __init__(self, curve_type="bls12_381"):
+    def __init__(self, curve_type="bls12_381", device=None):
         self.kzg = KZG(curve_type)
-        self.alg = DeviceAlgebra(curve_type)
+        self.alg = DeviceAlgebra(curve_type, device)
 
     def preprocess(self, qM, qL, qR, qO, qC, perm, tau=None):
         kzg, Fq, alg = self.kzg, self.kzg.Fq, self.alg
@@ -298,9 +305,9 @@ class DeviceProver:
             return alg.upload_parts(n, parts)
         b = [int(Fq.random_element()) for _ in range(11)] if blinders is None else [int(v) % r for v in blinders]
         assert len(b) == 11
-        if sh is not None and sh.world > 1:
+        if sh is not None and sh.active:
             b = sh.shared_scalars(b)                                          # drawn once, by rank 0
-        dealt = sh is not None and sh.world > 1 and sh.deal_transforms
+        dealt = sh is not None and sh.active and sh.deal_transforms
         D = self._domain_constants(n, g)
         ones, idH = D["ones"], D["idH"]                                       # 1 and g^i on H
 

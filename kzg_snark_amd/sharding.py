@@ -201,6 +201,11 @@ class ProofSharding:
     def rank(self):
         return dist.get_rank(self.group) if dist.is_initialized() else 0
 
+    @property
+    def active(self):
+        """more than one rank -- or a one-rank rehearsal that wants every collective issued (FORCE_COLLECTIVES)"""
+        return self.world > 1 or FORCE_COLLECTIVES
+
     def owner(self, i):
         return i % self.world
 
@@ -254,7 +259,7 @@ class ProofSharding:
         for i, shape in enumerate(shapes):
             own = self.owner(i) == self.rank
             t = compute(i) if own else torch.empty(shape, dtype=like.dtype, device=like.device)
-            if self.world > 1:
+            if self.active:
                 self.exchanges += 1
                 src = dist.get_global_rank(self.group, self.owner(i)) if self.group is not None else self.owner(i)
                 if t.is_cuda and not on_gpu:         # rehearsal on one GPU: gloo moves host memory only

@@ -79,5 +79,32 @@ def test_one_rank_rccl_group_takes_the_calls_the_multi_gpu_paths_make():
             ctx.synchronize()
             assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
         ctx.bind_torch_stream(torch.cuda.default_stream(dev))
+
+        # BASELINE config 5 over ranks (sharding.ProofSharding): the frozen 16-gate proof through the device prover with
+        # every exchange issued as an RCCL collective in this one-rank group -- the record gathers of the rounds, the
+        # blinders, and (deal_transforms) the eight broadcasts of device tensors
+        import json
+        from kzg_snark_amd import plonk, plonk_device, sharding
+        here = os.path.dirname(os.path.abspath(__file__))
+        gp = json.load(open(os.path.join(here, "golden", "plonk_proof_n16.json")))
+        g16 = json.load(open(os.path.join(here, "golden", "plonk_instance_n16.json")))
+        col = {k: [int(x, 16) for x in v] for k, v in g16["columns"].items()}
+        w_full = col["a"] + col["b"] + col["c"]
+        sharding.FORCE_COLLECTIVES = True
+        try:
+            idx = plonk_device.DeviceIndexer(gp["curve"])
+            ipk, ivk = idx.preprocess(col["qM"], col["qL"], col["qR"], col["qO"], col["qC"], g16["perm"],
+                                      tau=int(gp["tau"], 16))
+            for deal in (False, True):
+                sh = sharding.ProofSharding(deal_transforms=deal)
+                prv = plonk_device.DeviceProver(gp["curve"], alg=idx.alg, sharding=sh)
+                proof = prv.prove(ipk, w_full[:5], w_full[5:], blinders=[int(v, 16) for v in gp["blinders"]])
+                for k, v in gp["proof"]["commitments"].items():
+                    assert tuple(int(c) for c in proof["commitments"][k]) == (int(v[0], 16), int(v[1], 16), v[2]), k
+                for k, v in gp["proof"]["kzg_proofs"].items():
+                    assert tuple(int(c) for c in proof["kzg_proofs"][k]) == (int(v[0], 16), int(v[1], 16), v[2]), k
+                assert plonk.Verifier(gp["curve"]).verify(ivk, w_full[:5], proof)
+        finally:
+            sharding.FORCE_COLLECTIVES = False
     finally:
         dist.destroy_process_group()

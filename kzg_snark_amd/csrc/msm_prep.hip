@@ -62,9 +62,12 @@ constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk (bins
 #define KZG_PREP_STAGE_CAP 7168
 #endif
 #ifndef KZG_PREP_SWEEPS
-#define KZG_PREP_SWEEPS 1
+#define KZG_PREP_SWEEPS 2
 #endif
-constexpr uint32_t SWEEPS = KZG_PREP_SWEEPS;         // bin ranges the partition-1 scatter walks its chunk for (1: all at once)
+// Bin ranges the partition-1 scatter walks its chunk for.  Two sweeps of 1024 bins: WRITE_SIZE 374 -> ~330 MB per commit,
+// partition 1 alone 0.190 -> 0.169 ms, +1.5 % commits/s (same box, alternating; four sweeps 282 MB but no faster, eight
+// slower: the digits are extracted once per sweep) -- profiles/r03_scatter1_ab.txt
+constexpr uint32_t SWEEPS = KZG_PREP_SWEEPS;
 constexpr uint32_t STAGE_CAP = KZG_PREP_STAGE_CAP;   // entries a bin may have to be sorted in LDS: 28 KiB of table indices
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk
 constexpr uint32_t NCLS = 256;    // length classes
@@ -191,8 +194,9 @@ __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scal
   for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + chunk];
   __syncthreads();
   const uint32_t base = chunk * CH1;
-  // SWEEPS > 1 (experiment switch): the chunk is walked once per range of NBIN / SWEEPS bins, so that a workgroup has
-  // fewer runs open at a time (its scalars come from L2 after the first walk; the digits are extracted again)
+  // the chunk is walked once per range of NBIN / SWEEPS bins, so that a workgroup has fewer runs open at a time and
+  // more of its 8-byte stores meet in L2 before their line leaves (its scalars come from L2 after the first walk; the
+  // digits are extracted again)
   for (uint32_t sweep = 0; sweep < SWEEPS; ++sweep) {
     const uint32_t b_lo = sweep * (P::NBIN / SWEEPS), b_hi = b_lo + P::NBIN / SWEEPS;
     for (uint32_t it = 0; it < CH1 / TPB; ++it) {

@@ -117,6 +117,52 @@ __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
   store_words<F>(out + (size_t)t * 8, acc);
 }
 
+// The same with the bottom level of the evaluation fused in (round 3): beside comb[t] the workgroup also leaves
+// h1[c] = sum_{j < SC} comb[c*SC + j] * z^j for its 256 / SC chunks, so the scan does not read the combination a second
+// time for that.  Each thread multiplies its coefficient by z^(t mod SC) (table in LDS), the SC products of a chunk are
+// added lazily by its first lane (SC * 2p stays far below 2^261 and SC limbs of 29 bits below 2^32) and reduced once.
+struct ZPowArgs {
+  uint32_t l[SC * FRN];      // z^0 .. z^(SC-1), Montgomery form
+};
+template <class F>
+__global__ __launch_bounds__(256) void lincomb_eval_kernel(LincombArgs a, ZPowArgs zp, uint32_t* out, uint32_t n,
+                                                           uint32_t* h1) {
+  using Fd = Field<F>;
+  static_assert(F::N == FRN && 256 % SC == 0 && SC <= 8, "chunk layout of the fused evaluation");
+  __shared__ uint32_t zs[SC * FRN];
+  __shared__ uint32_t es[256 * FRN];                         // stride 9 words: conflict-free across consecutive lanes
+  const uint32_t tid = threadIdx.x;
+  const uint32_t t = blockIdx.x * 256 + tid;
+  if (tid < SC * FRN) zs[tid] = zp.l[tid];
+  Fe<F> acc = Fd::zero();
+  if (t < n) {
+    for (uint32_t i0 = 0; i0 < a.k; i0 += DOT_G) {
+      const uint32_t cnt = min(DOT_G, a.k - i0);
+      Fe<F> c[DOT_G], x[DOT_G];
+#pragma unroll
+      for (uint32_t g = 0; g < DOT_G; ++g) {
+        const uint32_t i = i0 + g;
+        const bool on = g < cnt && t < a.lens[i];
+        c[g] = on ? load_words<F>(a.polys + (a.stride * i + t) * 8) : Fd::zero();
+        x[g] = load_limbs<F>(a.xipow + (g < cnt ? i : i0) * F::N);
+      }
+      const Fe<F> part = dot_upto<F>(cnt, c, x);
+      acc = i0 ? Fd::add(acc, part) : part;
+    }
+    store_words<F>(out + (size_t)t * 8, acc);
+  }
+  __syncthreads();
+  const Fe<F> e = Fd::mul(acc, load_limbs<F>(zs + (tid & (SC - 1)) * F::N));      // 0 beyond the polynomial's end
+  store_limbs<F>(es + tid * F::N, e);
+  __syncthreads();
+  if ((tid & (SC - 1)) == 0 && t < n) {
+    Fe<F> sum = e;
+#pragma unroll
+    for (uint32_t j = 1; j < SC; ++j) sum = Fd::add_lazy(sum, load_limbs<F>(es + (tid + j) * F::N));
+    store_limbs<F>(h1 + (size_t)(t / SC) * F::N, Fd::reduce_wide(Fd::carry(sum)));
+  }
+}
+
 // bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*SC)
 template <class F, bool WORDS_IN>
 __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* h) {
@@ -182,13 +228,65 @@ __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size
   if (acc) atomicOr(flag, 1u);
 }
 
+// The last fill (coefficients in, quotient out) through LDS (round 3): a workgroup loads its FILL_EPB consecutive
+// coefficients with fully coalesced 16-byte accesses, every thread walks its SC-element chunk in LDS (one pad quad per
+// chunk spreads the 256-byte lane stride over the banks), and the suffix values leave coalesced again -- S[j] goes to
+// S_base + j (S_0 = the evaluation, S_j = quotient coefficient j-1: one contiguous vector, see the buffer layout).
+// The round-2 kernel read and wrote 32-byte elements at 256-byte lane strides: 1.7x / 1.55x the bytes (r03_open_pmc.csv).
+constexpr uint32_t FILL_TB = 128, FILL_EPB = FILL_TB * SC;
+template <class F>
+__global__ __launch_bounds__(FILL_TB) void chunk_fill_final_kernel(const uint32_t* in, uint32_t m, FrArg zpow,
+                                                                    const uint32_t* S_up, uint32_t* S_base) {
+  using Fd = Field<F>;
+  __shared__ uint4 st[FILL_EPB * 2 + FILL_TB];
+  const uint32_t tid = threadIdx.x, e0 = blockIdx.x * FILL_EPB;
+  const uint4* gin = reinterpret_cast<const uint4*>(in);
+  for (uint32_t i = tid; i < FILL_EPB * 2; i += FILL_TB) {
+    const uint32_t e = i >> 1;
+    if (e0 + e < m) st[i + (e >> SC_LOG)] = gin[(size_t)(e0 + e) * 2 + (i & 1)];
+  }
+  __syncthreads();
+  const uint32_t t = blockIdx.x * FILL_TB + tid;
+  const uint32_t j0 = t * SC;
+  if (j0 < m) {
+    const uint32_t j1 = min(j0 + SC, m);
+    const Fe<F> z = load_limbs<F>(zpow.l);
+    Fe<F> acc = load_limbs<F>(S_up + (size_t)(t + 1) * F::N);
+    for (uint32_t j = j1; j-- > j0;) {
+      const uint32_t q = (j - e0) * 2 + tid;                 // (j - e0) >> SC_LOG == tid
+      const uint4 lo = st[q], hi = st[q + 1];
+      const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      acc = Fd::add(Fd::from_words(w), Fd::mul(acc, z));
+      uint32_t o[8];
+      Fd::to_words(Fd::reduce(acc), o);
+      st[q] = make_uint4(o[0], o[1], o[2], o[3]);
+      st[q + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+  }
+  __syncthreads();
+  uint4* gout = reinterpret_cast<uint4*>(S_base);
+  for (uint32_t i = tid; i < FILL_EPB * 2; i += FILL_TB) {
+    const uint32_t e = i >> 1;
+    if (e0 + e < m) gout[(size_t)(e0 + e) * 2 + (i & 1)] = st[i + (e >> SC_LOG)];
+  }
+}
+
 // Buffer layout of poly_tmp[0] (canonical words, 8 per element), cap = n + 1:
 //   comb[0 .. cap)   combined polynomial (+ one optional appended top coefficient)
 //   eval             S_0
 //   quot[0 .. cap)   S_1, S_2, ...        => [eval, quot...] is the contiguous vector S_0, S_1, ...
+// total entries of the levels above the coefficients (h_1 .. h_(nl-1)) for n coefficients
+static size_t scan_level_entries(size_t n) {
+  size_t total = 0;
+  for (size_t m = n; m > SC;) { m = (m + SC - 1) / SC; total += m; }
+  return total;
+}
+
+// z_words given: the bottom level of the evaluation at z is fused into the combination (h_1 lands at the start of
+// poly_tmp[2], where open_scan_t(.., h1_ready = true) expects it).
 template <class F>
 int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
-                   const uint32_t* xi_words, size_t* n_out) {
+                   const uint32_t* xi_words, size_t* n_out, const uint32_t* z_words = nullptr) {
   using Fd = Field<F>;
   if (k > MAXK) return set_err(c, KZG_ERR_ARG, "kzg_open: more than 64 polynomials");
   size_t n = 0;
@@ -212,8 +310,22 @@ int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k
     memcpy(&la.xipow[i * F::N], xp.l, F::N * 4);
     la.lens[i] = (uint32_t)lens[i];
   }
-  hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_comb,
-                     (uint32_t)n);
+  if (z_words && n > SC) {
+    if ((rc = ensure_buf(c, c->poly_tmp[2], (scan_level_entries(n) + 1) * F::N * 4))) return rc;
+    ZPowArgs zp{};
+    const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
+    Fe<F> zj = Fd::one();
+    for (uint32_t j = 0; j < SC; ++j) {
+      const Fe<F> zr = Fd::reduce(zj);
+      memcpy(&zp.l[j * F::N], zr.l, F::N * 4);
+      zj = Fd::mul(zj, z);
+    }
+    hipLaunchKernelGGL(lincomb_eval_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, zp,
+                       d_comb, (uint32_t)n, static_cast<uint32_t*>(c->poly_tmp[2].p));
+  } else {
+    hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_comb,
+                       (uint32_t)n);
+  }
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
 }
@@ -222,7 +334,8 @@ int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k
 // eval_out: host memory that receives S_0 (the call then synchronises the stream), or nullptr: nothing is copied and
 // nothing waits -- the pipelined open fetches the 32 bytes at comb + cap*8 itself (msm.hip, commit_device).
 template <class F>
-int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out, bool sync = true) {
+int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out, bool sync = true,
+                bool h1_ready = false) {
   using Fd = Field<F>;
   std::vector<uint32_t> m{(uint32_t)n};
   while (m.back() > SC) m.push_back((m.back() + SC - 1) / SC);
@@ -253,14 +366,16 @@ int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t*
     uint32_t* hp = d_h; uint32_t* sp = d_S;
     for (size_t l = 1; l < nl; ++l) { hptr[l] = hp; hp += (size_t)m[l] * F::N; sptr[l] = sp; sp += (size_t)(m[l] + 1) * F::N; }
   }
+  (void)d_quot;
   if (nl == 1) {
     // n <= SC: a single chunk; its carry is zero.  Use a one-entry zero suffix array.
     KZG_HIP(c, hipMemsetAsync(d_S, 0, 2 * F::N * 4, c->stream));
-    hipLaunchKernelGGL((chunk_fill_kernel<F, true>), dim3(1), dim3(64), 0, c->stream, d_comb, m[0], zpow(0), d_S,
-                       (uint32_t*)nullptr, d_quot, d_eval);
+    hipLaunchKernelGGL(chunk_fill_final_kernel<F>, dim3(1), dim3(FILL_TB), 0, c->stream, d_comb, m[0], zpow(0), d_S,
+                       d_eval);
   } else {
-    hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, d_comb, m[0],
-                       zpow(0), hptr[1]);
+    if (!h1_ready)     // (the fused combination of open_quotient_t has left h_1 already)
+      hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, d_comb, m[0],
+                         zpow(0), hptr[1]);
     for (size_t l = 1; l + 1 < nl; ++l)
       hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
                          m[l], zpow(l), hptr[l + 1]);
@@ -269,8 +384,8 @@ int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t*
     for (size_t l = nl - 2; l >= 1; --l)
       hipLaunchKernelGGL((chunk_fill_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
                          m[l], zpow(l), sptr[l + 1], sptr[l], (uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL((chunk_fill_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, d_comb, m[0],
-                       zpow(0), sptr[1], (uint32_t*)nullptr, d_quot, d_eval);
+    hipLaunchKernelGGL(chunk_fill_final_kernel<F>, dim3((m[0] + FILL_EPB - 1) / FILL_EPB), dim3(FILL_TB), 0, c->stream,
+                       d_comb, m[0], zpow(0), sptr[1], d_eval);
   }
   KZG_HIP(c, hipGetLastError());
   if (eval_out) {
@@ -289,10 +404,10 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
   *quot_len = 0;
   *d_quot_out = nullptr;
   size_t n = 0;
-  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n);
+  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n, z_words);
   if (rc) return rc;
   if (n == 0) return KZG_OK;     // all polynomials zero: witness 0, evaluation 0
-  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, sync ? eval_out : nullptr, sync))) return rc;
+  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, sync ? eval_out : nullptr, sync, /*h1_ready=*/n > SC))) return rc;
   *d_quot_out = static_cast<uint32_t*>(c->poly_tmp[0].p) + (n + 1) * 8 + 8;
   *quot_len = n - 1;
   return KZG_OK;

@@ -16,7 +16,8 @@ tag = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_open_" + tag)
 dst = os.path.join(ROOT, "profiles")
-POLY = ("lincomb_kernel", "chunk_eval_kernel", "chunk_fill_kernel", "top_suffix_kernel")
+POLY = ("lincomb_kernel", "lincomb_eval_kernel", "chunk_eval_kernel", "chunk_fill_kernel", "chunk_fill_final_kernel",
+        "top_suffix_kernel")
 
 
 def short(name):
@@ -30,7 +31,7 @@ def one(pattern):
 
 
 rows = list(csv.DictReader(open(one("trace/**/*kernel_stats.csv"))))
-n_open = next(int(r["Calls"]) for r in rows if short(r["Name"]) == "lincomb_kernel")     # one lincomb per opening
+n_open = sum(int(r["Calls"]) for r in rows if short(r["Name"]) in ("lincomb_kernel", "lincomb_eval_kernel"))   # one per opening
 with open(os.path.join(dst, f"{tag}_open_kernel_stats.csv"), "w") as f:
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns,calls_per_opening,ns_per_opening\n")
     for r in rows:

@@ -770,6 +770,8 @@ def main(argv=None):
         run_section("plonk_round", section_plonk, env)
 
     coll_info = env.collectives_info()      # a collective: every rank takes part
+    # the NTT half of the metric over all ranks: every rank ran the same loop on its own GPU; the slowest rank's time
+    ntt_pass_s_all = env.max_over_ranks(ntt_alone[0] / max(ntt_alone[1], 1) * 1e-3)
     spans = dict(spans_main)
     spans["ntt_pass"] = (ntt_alone[0] * args.steps / ntt_iters, ntt_alone[1] * args.steps // ntt_iters)
     if rank == 0:
@@ -778,7 +780,7 @@ def main(argv=None):
         msm_bytes = n * (32 + 2 * fp_bytes)                 # scalars + affine points, per commit
         ntt_ms, ntt_cnt = ntt_alone
         # one launch covers the whole batch; two launches (passes) per transform above 2^12
-        ntt_per_transform_s = (ntt_ms / max(ntt_cnt, 1)) * (2e-3 if log_n > 12 else 1e-3) / B
+        ntt_per_transform_s = ntt_pass_s_all * (2 if log_n > 12 else 1) / B
         ntt_bytes = 2 * n * 32                              # read + write every element once
         acc_alone_s = acc_alone[0] / max(acc_alone[1], 1) * 1e-3
         out = {
@@ -803,7 +805,8 @@ def main(argv=None):
             # what the process group really was (a SCALE record then shows that RCCL saw N ranks, one GPU each)
             "collectives": coll_info,
             "build": env.build_info(),
-            "ntt_elements_per_s": n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
+            # whole job: every rank transforms its own polynomials (slowest rank's time per transform)
+            "ntt_elements_per_s": world * n / ntt_per_transform_s if ntt_per_transform_s > 0 else None,
             "ntt_ms": ntt_per_transform_s * 1e3,
             "kernel_ms_per_commit": {k: (v[0] / (args.steps * B)) for k, v in spans.items()},
             # the same spans with ONE commit in flight (nothing else on the GPU): each stage's own duration

@@ -64,9 +64,10 @@ constexpr uint32_t CH2 = KZG_PREP_CH2;    // entries per partition-2 chunk (bins
 #ifndef KZG_PREP_SWEEPS
 #define KZG_PREP_SWEEPS 2
 #endif
-// Bin ranges the partition-1 scatter walks its chunk for.  Two sweeps of 1024 bins: WRITE_SIZE 374 -> ~330 MB per commit,
-// partition 1 alone 0.190 -> 0.169 ms, +1.5 % commits/s (same box, alternating; four sweeps 282 MB but no faster, eight
-// slower: the digits are extracted once per sweep) -- profiles/r03_scatter1_ab.txt
+// Bin ranges the partition-1 scatter walks its chunk for.  Two sweeps of 1024 bins: partition 1 alone 0.190 -> 0.169 ms,
+// +1.5 % commits/s (same box, alternating, twice) at an unchanged WRITE_SIZE (374 -> 379 MB per commit; four sweeps
+// write 282 MB and are no faster, eight are slower: the digits are extracted once per sweep) --
+// profiles/r03_scatter1_ab.txt, profiles/r03_pmc.csv
 constexpr uint32_t SWEEPS = KZG_PREP_SWEEPS;
 constexpr uint32_t STAGE_CAP = KZG_PREP_STAGE_CAP;   // entries a bin may have to be sorted in LDS: 28 KiB of table indices
 constexpr uint32_t CHL = 2048;    // buckets per ordering chunk

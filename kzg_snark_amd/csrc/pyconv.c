@@ -32,7 +32,13 @@ static PyObject* ints_to_bytes(PyObject* self, PyObject* args) {
       if (!owned) goto fail;
       item = owned;
     }
+    /* CPython 3.13 added a `with_exceptions` argument to this private function (build.py treats the helper as
+     * optional: should a later CPython change it again, the build warns and the pure-Python conversion is used) */
+#if PY_VERSION_HEX >= 0x030D0000
+    const int rc = _PyLong_AsByteArray((PyLongObject*)item, p + i * nb, (size_t)nb, 1 /* little */, 0 /* unsigned */, 1);
+#else
     const int rc = _PyLong_AsByteArray((PyLongObject*)item, p + i * nb, (size_t)nb, 1 /* little */, 0 /* unsigned */);
+#endif
     Py_XDECREF(owned);
     if (rc < 0) goto fail;
   }

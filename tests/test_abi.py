@@ -59,3 +59,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
+
+
+def test_build_is_keyed_on_what_it_is_built_from(built, monkeypatch):
+    """kzg_snark_amd/build.py rebuilds a translation unit when the hash of its source, the headers, the flags and the
+    compiler changes -- not when a file time does -- and says which of the two it did."""
+    from kzg_snark_amd import build
+    stamp = build._read_stamp()
+    assert stamp.get("source_hash") == build.source_hash()          # the library in the tree is built from these sources
+    assert set(stamp.get("units", {})) == set(build.SOURCES)
+    assert all(stamp["units"][u] == build.source_hash(u) for u in build.SOURCES)
+    assert build.source_hash("ntt.hip") != build.source_hash("msm.hip")
+    build.build(verbose=False)                                       # nothing changed: nothing compiled
+    assert build.LAST["mode"] == "reused" and build.LAST["compiled"] == []
+    os.utime(os.path.join(build.CSRC, "ntt.hip"))                    # a newer file time alone changes nothing
+    build.build(verbose=False)
+    assert build.LAST["mode"] == "reused"
+    before = build.source_hash("ntt.hip")
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DKZG_SOME_SWITCH=1"])
+    assert build.source_hash("ntt.hip") != before                    # flags are part of the key

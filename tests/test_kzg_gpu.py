@@ -620,3 +620,36 @@ def test_commit_2_20_with_extreme_coefficients(native, kzgs):
     got = native.limbs_to_ints(xy.reshape(2, 6))
     sp = native.limbs_to_ints(sparse)
     assert inf[0] == 0 and (got[0], got[1]) == O.normalize(O.commit_trapdoor(sp, tau, cv), cv)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_open_at_the_tile_boundaries_of_its_kernels(native, kzgs, curve):
+    """The combination groups six products per reduction (Field::dot), its workgroup of 256 coefficients also leaves the
+    bottom level of the evaluation, and the last fill works on tiles of 1024: k = 1 .. 13 polynomials (one to three
+    groups, every remainder) of lengths around those tile sizes, coefficients r-1 / 0 / random, against the trapdoor
+    identity open == ((P(tau) - P(z)) / (tau - z)) G1 and P(z) against the oracle's Horner (kzg.py:148-154)."""
+    cv = O.curve(curve)
+    r = cv.r
+    kzg = kzgs[curve]
+    tau = 0xfeedface12345 % r
+    ck, _ = kzg.setup(2100, tau=tau)
+    ctx = native.get_context(curve)
+    rng = random.Random(1234)
+    L = ctx.fp_limbs
+    for n, k in ((255, 1), (256, 2), (257, 3), (1023, 4), (1024, 5), (1025, 6), (2049, 7), (9, 8), (8, 9), (513, 11), (2047, 13)):
+        lens = [max(1, n - 3 * i) for i in range(k)]
+        polys = []
+        for i, m in enumerate(lens):
+            kind = (i + n) % 3
+            polys.append([r - 1] * m if kind == 0 else [rng.randrange(r) for _ in range(m)] if kind == 1
+                         else [(r - 1) if j % 2 else 0 for j in range(m)])
+        arr = np.zeros((k, n, 4), dtype=np.uint64)
+        for i, p in enumerate(polys):
+            arr[i, :len(p)] = native.ints_to_limbs(p)
+        z, xi = (r - 1, r - 1) if n % 2 else (rng.randrange(r), rng.randrange(r))
+        xy, inf, ev = ctx.open(ck.srs, arr, lens, n, native.int_to_words(z), native.int_to_words(xi))
+        comb = O.combine(polys, xi, r)
+        assert native.limbs_to_ints(ev.reshape(1, 4))[0] == O.poly_eval(comb, z, r), (n, k)
+        want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
+        got = None if inf[0] else tuple(native.limbs_to_ints(xy.reshape(2, L)))
+        assert got == want, (n, k)

@@ -67,6 +67,16 @@ def test_constants():
         assert pow(w, 1 << 19, cv.r) == cv.r - 1
     assert O.BLS12_381.root_of_unity(1 << 20) == 0x3e1c54bcb947035a57a6e07cb98de4a2f69e02d265e09d9fece7e0e39898d4b
     assert O.BN254.root_of_unity(1 << 20) == 0x26125da10a0ed06327508aba06d1e303ac616632dbed349f53422da953337857
+    # Published constants, independent of this repository: the 2-adic roots of unity the pairing libraries ship for
+    # these scalar fields (arkworks / bellman `TWO_ADIC_ROOT_OF_UNITY`: generator^((r-1)/2^s) with the smallest
+    # primitive root 7 resp. 5 -- the element Sage's Fq(1).nth_root(2^s) is recalled to return).
+    # Every domain generator of the facade is a power of these.
+    assert O.BLS12_381.root_of_unity(1 << 32) == \
+        10238227357739495823651030575849232062558860180284477541189508159991286009131
+    assert O.BN254.root_of_unity(1 << 28) == \
+        19103219067921713944291392827692070036145651957329286315305642004821462161904
+    assert O.BLS12_381.root_of_unity(1 << 20) == pow(O.BLS12_381.root_of_unity(1 << 32), 1 << 12, O.BLS12_381.r)
+    assert O.BN254.root_of_unity(1 << 20) == pow(O.BN254.root_of_unity(1 << 28), 1 << 8, O.BN254.r)
 
 
 def test_known_answer_points():

@@ -555,24 +555,28 @@ __global__ void vec_lincomb_kernel(ScalarLincombArgs a, uint32_t* out, uint32_t 
 // out[i] = a[i] * c * s^i : thread handles LC consecutive i (one pow per chunk, then a running product)
 struct PowArgs {
   uint32_t s[FR_LIMBS], c[FR_LIMBS];   // Montgomery form, in the kernel arguments
+  uint32_t step[FR_LIMBS];             // s^(threads of the launch)
 };
+// Thread t takes the elements t, t + T, t + 2T, .. (T = threads of the launch): consecutive lanes touch consecutive
+// 32-byte elements (round 2 gave a thread LC consecutive elements -- a 1 KB lane stride, four times the bytes through
+// the memory system and 0.5 ms per 2^22 elements in the prover's coset shifts).  p = c * s^t by square-and-multiply
+// once, then p *= s^T per element (sc.step, computed by the host).
 template <class F>
 __global__ void vec_mul_powers_kernel(size_t n, const uint32_t* a, PowArgs sc, uint32_t* out) {
   using Fd = Field<F>;
   static_assert(F::N == FR_LIMBS, "scalar fields have 9 limbs");
+  const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i0 = t * LC;
-  if (i0 >= n) return;
-  const Fe<F> s = load_limbs<F>(sc.s);
-  Fe<F> b = s, p = load_limbs<F>(sc.c);                 // p = c (Montgomery)
-  for (size_t bits = i0; bits; bits >>= 1) {            // p = c * s^i0
+  if (t >= n) return;
+  Fe<F> b = load_limbs<F>(sc.s), p = load_limbs<F>(sc.c);   // p = c (Montgomery)
+  for (size_t bits = t; bits; bits >>= 1) {                 // p = c * s^t
     if (bits & 1u) p = Fd::mul(p, b);
     b = Fd::mul(b, b);
   }
-  const size_t i1 = i0 + LC < n ? i0 + LC : n;
-  for (size_t i = i0; i < i1; ++i) {
+  const Fe<F> step = load_limbs<F>(sc.step);
+  for (size_t i = t; i < n; i += T) {
     store_words<F>(out + i * 8, Fd::mul(load_words<F>(a + i * 8), p));
-    p = Fd::mul(p, s);
+    p = Fd::mul(p, step);
   }
 }
 
@@ -585,25 +589,27 @@ __global__ void vec_inverse_fermat_kernel(size_t n, const uint32_t* a, uint32_t*
   const Fe<F> x = Fd::to_mont(load_words<F>(a + i * 8));
   store_words<F>(out + i * 8, Fd::from_mont(Fd::inv(x)));
 }
-// The same by batch inversion (Montgomery's trick) over the LC consecutive elements of a thread: the
-// output buffer first receives the running products of the non-zero elements (Montgomery form), one
-// exponentiation inverts the chunk product, and the backward sweep peels the inverses off:
+// The same by batch inversion (Montgomery's trick) over LC elements per thread -- the elements t, t + T, t + 2T, ..
+// (T = threads of the launch), so that consecutive lanes touch consecutive elements (round 2 batched LC CONSECUTIVE
+// elements: a 1 KB lane stride).  The output buffer first receives the running products of the non-zero elements
+// (Montgomery form), one exponentiation inverts the batch product, and the backward sweep peels the inverses off:
 // 5 multiplications per element + 1/LC of an exponentiation instead of a whole one (~380).
 template <class F>
 __global__ void vec_inverse_kernel(size_t n, const uint32_t* a, uint32_t* out) {
   using Fd = Field<F>;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i0 = t * LC;
-  if (i0 >= n) return;
-  const size_t i1 = i0 + LC < n ? i0 + LC : n;
+  if (t >= n) return;
   Fe<F> acc = Fd::one();
-  for (size_t i = i0; i < i1; ++i) {
-    store_words<F>(out + i * 8, acc);                       // product of the non-zero elements before i
+  size_t last = t;
+  for (size_t i = t; i < n; i += T) {
+    store_words<F>(out + i * 8, acc);                       // product of the non-zero elements of the batch before i
     const Fe<F> x = Fd::to_mont(load_words<F>(a + i * 8));
     if (!Fd::is_zero(x)) acc = Fd::mul(acc, x);
+    last = i;
   }
   Fe<F> inv = Fd::inv(acc);                                 // acc is a product of non-zero elements (or one)
-  for (size_t i = i1; i-- > i0;) {
+  for (size_t i = last;; i -= T) {
     const Fe<F> x = Fd::to_mont(load_words<F>(a + i * 8));
     if (Fd::is_zero(x)) {
       store_words<F>(out + i * 8, Fd::zero());
@@ -612,6 +618,7 @@ __global__ void vec_inverse_kernel(size_t n, const uint32_t* a, uint32_t* out) {
       store_words<F>(out + i * 8, Fd::from_mont(Fd::mul(inv, pre)));
       inv = Fd::mul(inv, x);
     }
+    if (i == t) break;
   }
 }
 
@@ -698,9 +705,14 @@ int vec_mul_powers_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* s_word
   PowArgs sc;
   memcpy(sc.s, s.l, F::N * 4);
   memcpy(sc.c, cc.l, F::N * 4);
-  const size_t chunks = (n + LC - 1) / LC;
-  hipLaunchKernelGGL(vec_mul_powers_kernel<F>, dim3((uint32_t)((chunks + 127) / 128)), dim3(128), 0, c->stream, n, a,
-                     sc, out);
+  // LC elements per thread; the thread count is a power of two so that s^T is log2(T) squarings on the host
+  uint32_t lt = 7;
+  while (((size_t)LC << lt) < n && lt < 24) ++lt;
+  const size_t T = (size_t)1 << lt;
+  Fe<F> step = s;
+  for (uint32_t q = 0; q < lt; ++q) step = Fd::mul(step, step);
+  memcpy(sc.step, step.l, F::N * 4);
+  hipLaunchKernelGGL(vec_mul_powers_kernel<F>, dim3((uint32_t)(T / 128)), dim3(128), 0, c->stream, n, a, sc, out);
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
 }

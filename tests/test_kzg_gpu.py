@@ -653,3 +653,37 @@ def test_open_at_the_tile_boundaries_of_its_kernels(native, kzgs, curve):
         want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
         got = None if inf[0] else tuple(native.limbs_to_ints(xy.reshape(2, L)))
         assert got == want, (n, k)
+
+
+@pytest.mark.parametrize("key_log", [15, 18])
+def test_bins_at_the_edge_of_the_sort_stage(native, kzgs, key_log):
+    """Partition 2 sorts a bin of <= 7168 entries in one workgroup (registers + LDS stage) and hands a larger one to
+    the chunked kernels (csrc/msm_prep.hip): bins holding exactly 7168, 7169, 7167, 1 and 0 entries side by side, for
+    the 16-bit-window path (keys below 2^18 points) and the 20-bit one.  A scalar v in [1, 2^15] is ONE digit, in
+    window 0, bucket v-1, bin (v-1) >> 8; trapdoor identity on the result (kzg.py:112-116)."""
+    cv = O.BLS12_381
+    r = cv.r
+    ctx = native.get_context("bls12_381")
+    n_key = 1 << key_log
+    tau = 0x1357924680 % r
+    srs = ctx.srs_generate(native.int_to_words(tau), n_key)
+    rs = np.random.RandomState(key_log)
+    vals = []
+    for b, cnt in ((0, 7168), (1, 7169), (2, 7167), (3, 1), (5, 300)):
+        vals += list(rs.randint(256 * b + 1, 256 * b + 257, size=cnt))
+    vals = np.array(vals, dtype=np.uint64)
+    rs.shuffle(vals)
+    n = len(vals) + 500                                                  # the tail: zero scalars (skipped, kzg.py:113-114)
+    raw = np.zeros((n, 4), dtype=np.uint64)
+    raw[:len(vals), 0] = vals
+    xy, inf = ctx.commit(srs, raw.reshape(1, n, 4), [n], n)
+    coeffs = [int(v) for v in raw[:, 0]]
+    got = tuple(native.limbs_to_ints(xy.reshape(2, 6)))
+    assert inf[0] == 0 and got == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv)
+    # and negative digits of the same magnitudes (r - v): every window is non-zero, window 0 mirrors the above
+    neg = native.ints_to_limbs([(r - int(v)) % r for v in raw[:, 0]])
+    xy, inf = ctx.commit(srs, neg.reshape(1, n, 4), [n], n)
+    got = tuple(native.limbs_to_ints(xy.reshape(2, 6)))
+    want = O.normalize(O.commit_trapdoor([(r - c) % r for c in coeffs], tau, cv), cv)
+    assert inf[0] == 0 and got == want
+    srs.close()

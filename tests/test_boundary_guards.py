@@ -130,3 +130,15 @@ print("SUM", int(x[0, 0]))
     lines = out.stdout.split()
     assert "ADOPTED" not in lines and lines[lines.index("REFUSED") + 1] == "5", out.stdout
     assert lines[-2:] == ["SUM", "16"], out.stdout               # w = 1: X[0] = sum of sixteen ones
+
+
+def test_default_device_follows_the_environment(monkeypatch):
+    """One process per GPU: the facade's device is KZG_MI355X_DEVICE, else torch's current device once torch.cuda is up
+    (not on this CPU box), else 0."""
+    from kzg_snark_amd import _native
+    monkeypatch.delenv("KZG_MI355X_DEVICE", raising=False)
+    import torch
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        assert _native.default_device() == 0
+    monkeypatch.setenv("KZG_MI355X_DEVICE", "5")
+    assert _native.default_device() == 5

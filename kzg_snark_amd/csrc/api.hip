@@ -127,7 +127,7 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
   if (hip_stream) {
     // What can be checked is checked before the handle is adopted.  HIP offers no validation of a stream handle:
     // hipStreamQuery (like every other entry point) dereferences it -- a readable buffer that is no stream crashed the
-    // process on ROCm 7.2 (round 3, gpurun_out/r03_call2b_pytest.log).  So: the two documented aliases
+    // process on ROCm 7.2 (round 3, profiles/r03_stream_query_crash.log).  So: the two documented aliases
     // (hipStreamLegacy, hipStreamPerThread) are taken as such; any other small integer or misaligned value cannot be
     // a runtime object and is refused (the class of gpurun_out/r02_crash.log: an alias or enum value passed where a
     // handle belongs would reach hipEventRecord); a plausible pointer is then asked for its status, which surfaces

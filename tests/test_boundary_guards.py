@@ -97,7 +97,7 @@ def test_failed_open_leaves_no_stale_evaluation_pointer(native):
 def test_set_stream_refuses_what_cannot_be_a_stream():
     """gpurun_out/r02_crash.log: a non-handle passed to kzg_ctx_set_stream used to reach hipEventRecord.  HIP cannot
     validate a handle (hipStreamQuery dereferences it: a readable buffer that is no stream crashed the child of this
-    test's first version, gpurun_out/r03_call2b_pytest.log), so the library refuses what cannot be a runtime object
+    test's first version, profiles/r03_stream_query_crash.log), so the library refuses what cannot be a runtime object
     -- small integers other than the two documented aliases, misaligned values -- and takes real streams and the
     aliases.  Run in a child process: a regression here is a host crash, which must not take the session down."""
     code = r'''

@@ -87,6 +87,9 @@ int ensure_buf(Ctx* c, DevBuf& b, size_t bytes);
     if (e__ != hipSuccess) return set_err((c), KZG_ERR_HIP, #call, e__); \
   } while (0)
 
+// msm.hip: is an accumulate kernel of the commit pipeline queued or running?
+bool msm_accumulate_in_flight(Ctx* c);
+
 // ntt.hip
 int ntt_run_device(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_words, int inverse,
                    uint32_t batch);

@@ -742,6 +742,17 @@ static MsmWork* get_work(Ctx* c) {
   if (!c->msm_work) c->msm_work = new MsmWork();
   return static_cast<MsmWork*>(c->msm_work);
 }
+// true while a queued polynomial's accumulate kernel has not finished (its persistent workgroups hold 114 of a CU's
+// 160 KiB of LDS): what another kernel launched now would have to fit beside (ntt.hip: tile size)
+bool msm_accumulate_in_flight(Ctx* c) {
+  MsmWork* w = static_cast<MsmWork*>(c->msm_work);
+  if (!w) return false;
+  for (auto& sl : w->slot)
+    if (sl.pending && sl.ev_a && hipEventQuery(sl.ev_a) == hipErrorNotReady) return true;
+  (void)hipGetLastError();
+  return false;
+}
+
 void msm_free_work(Ctx* c) {
   MsmWork* w = static_cast<MsmWork*>(c->msm_work);
   if (!w) return;

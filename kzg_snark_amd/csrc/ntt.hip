@@ -426,14 +426,18 @@ int build_domain(Ctx* c, NttDomain& d) {
   return KZG_OK;
 }
 
-// preferred log2(tile elements): KZG_NTT_TILE_LOG = 10 | 11 | 12 (experiments); default 11
-static uint32_t tile_log_pref() {
-  static const uint32_t v = [] {
-    const char* e = getenv("KZG_NTT_TILE_LOG");
-    const int x = e ? atoi(e) : TILE_LOG_2WG;
-    return (uint32_t)std::min(std::max(x, 8), TILE_LOG);
-  }();
-  return v;
+// Preferred log2(tile elements).  Alone, 2048-element tiles (72 KiB, two 512-thread workgroups per CU) are fastest
+// (TILE_LOG_2WG).  While an accumulate kernel of the commit pipeline is queued or running, its four persistent
+// workgroups hold 114 of a CU's 160 KiB of LDS for ~2 ms: a 72 KiB tile then only gets CUs in that kernel's tail and the
+// NEXT accumulate kernel starts short of workgroups, whereas a 1024-element tile (36 KiB, 256 threads, one wave of <= 122
+// VGPRs per SIMD) fits beside them.  Round 3, same box, alternating, bench.py at B = 4: 464.6 / 460.9 commits/s with
+// 1024-element tiles against 432.3 / 439.2 (the NTT alone: 100.4 vs 99.0 us, HBM traffic per transform unchanged at
+// 2.04x algorithmic) -- so the tile follows what is resident.  KZG_NTT_TILE_LOG = 9 .. 12 fixes it (experiments).
+constexpr int TILE_LOG_BESIDE_MSM = 10;
+static uint32_t tile_log_pref(Ctx* c) {
+  static const int fixed = [] { const char* e = getenv("KZG_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();
+  const int x = fixed ? fixed : (msm_accumulate_in_flight(c) ? TILE_LOG_BESIDE_MSM : TILE_LOG_2WG);
+  return (uint32_t)std::min(std::max(x, 8), TILE_LOG);
 }
 
 template <class F>
@@ -457,11 +461,12 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
   }
   const uint32_t k1 = (log_n + 1) / 2, k2 = log_n - k1;
   const uint64_t N1 = 1ull << k1, N2 = 1ull << k2;
+  const uint32_t tile_pref = tile_log_pref(c);       // one choice for both passes of the transform
   int rc = ensure_buf(c, c->ntt_scratch, (size_t)n * batch * 32);
   if (rc) return rc;
   uint32_t* scratch = static_cast<uint32_t*>(c->ntt_scratch.p);
   {  // pass 1: columns of the N1 x N2 matrix, twist by w^(t*v)
-    const uint32_t tl = std::max<uint32_t>(k1, tile_log_pref());
+    const uint32_t tl = std::max<uint32_t>(k1, tile_pref);
     const uint32_t logC = std::min<uint32_t>(tl - k1, k2);
     NttPassArgs a{};
     a.ld_shift = a.st_shift = 31;
@@ -477,7 +482,7 @@ int launch_passes(Ctx* c, const NttDomain& d, uint32_t* d_data, uint32_t batch) 
     if (rc) return rc;
   }
   {  // pass 2: rows; row t, output index b -> out[b*N1 + t]
-    const uint32_t tl = std::max<uint32_t>(k2, tile_log_pref());
+    const uint32_t tl = std::max<uint32_t>(k2, tile_pref);
     const uint32_t logC = std::min<uint32_t>(tl - k2, k1);
     NttPassArgs a{};
     a.ld_shift = a.st_shift = 31;

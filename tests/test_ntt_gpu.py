@@ -368,3 +368,43 @@ def test_worst_case_values_through_the_lazy_levels(native, log_n, cases):
         want = vec.copy()
         CO.fft("bls12_381", want, w, inverse=inverse)
         assert np.array_equal(got, want), (log_n, hex(w)[:12], inverse)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_transform_beside_a_commit_in_flight(native, curve):
+    """While an accumulate kernel of the commit pipeline is queued or running the NTT takes 1024-element tiles that fit
+    beside its workgroups (ntt.hip, tile_log_pref); alone it takes 2048-element ones.  Same results either way, and
+    both equal the C restatement of fft_ff.py:15-37 (forward and inverse, 2^20; 2^13 for the odd split)."""
+    import torch
+    from oracle import c_oracle as CO
+    cv = O.curve(curve)
+    ctx = native.get_context(curve)
+    n_key = 1 << 20
+    srs = ctx.srs_generate(native.int_to_words(0x4242424242 % cv.r), n_key)
+    rs = np.random.RandomState(77)
+    sc = rs.randint(0, 1 << 62, size=(4, n_key, 4)).astype(np.uint64)
+    sc[:, :, 3] >>= np.uint64(3)
+    d_sc = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    L = ctx.fp_limbs
+    for log_n in (20, 13):
+        n = 1 << log_n
+        w = cv.root_of_unity(n)
+        ww = native.int_to_words(w)
+        raw = _plant_edge_values(_uniform_below_r(rs, n, cv.r), cv.r, native)
+        for inverse in (False, True):
+            want = raw.copy()
+            CO.fft(curve, want, w, inverse=inverse)
+            alone = torch.from_numpy(raw.view(np.int64)).to("cuda:0")
+            busy = alone.clone()
+            torch.cuda.synchronize()
+            ctx.ntt_device(alone.data_ptr(), log_n, ww, inverse, 1)                  # nothing in flight
+            ctx.synchronize()
+            xy, inf = np.zeros((4, 2 * L), dtype=np.uint64), np.zeros(4, dtype=np.uint8)
+            ctx.commit_device_async(srs, d_sc.data_ptr(), [n_key] * 4, n_key, xy, inf)   # four MSMs queued
+            ctx.ntt_device(busy.data_ptr(), log_n, ww, inverse, 1)                   # beside them
+            ctx.commit_flush()
+            ctx.synchronize()
+            assert np.array_equal(alone.cpu().numpy().view(np.uint64), want), (log_n, inverse, "alone")
+            assert np.array_equal(busy.cpu().numpy().view(np.uint64), want), (log_n, inverse, "beside a commit")
+            assert int(inf.sum()) == 0
+    srs.close()

@@ -37,14 +37,15 @@
 namespace kzg {
 namespace {
 
-template <int WB>
+template <int WB, int LOBV = 8>
 struct PW {
   static constexpr int NWIN = (256 + WB - 1) / WB;
   static constexpr uint32_t NB = 1u << (WB - 1);
-  static constexpr int LOB = 8;                           // low bucket bits: buckets per bin
+  static constexpr int LOB = LOBV;                        // low bucket bits: buckets per bin
   static constexpr uint32_t BPB = 1u << LOB;
-  static constexpr uint32_t NBIN = NB >> LOB;             // 2048 (c = 20) / 128 (c = 16): a uniform 2^20-scalar
-                                                          // commit puts 6.6 K entries into each bin
+  static constexpr uint32_t NBIN = NB >> LOB;             // LOB = 8: 2048 (c = 20) / 128 (c = 16) bins -- a uniform
+                                                          // 2^20-scalar commit puts 6.6 K entries into each bin;
+                                                          // LOB = 7 / 6 for up to 2^21 / 2^22 scalars (lob_for)
 };
 constexpr uint32_t TPB = 256;     // threads per workgroup, every kernel here
 #ifndef KZG_PREP_PRIO
@@ -112,10 +113,10 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
 // ---- partition 1 ------------------------------------------------------------------
 
 // hist1[bin][chunk] = entries of the chunk that fall into the bin
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_count1_kernel(const uint32_t* scalars, uint32_t n, uint32_t nchunk,
                                                           uint32_t* hist1) {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   side_priority();
   __shared__ uint32_t hist[P::NBIN];
   for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) hist[b] = 0;
@@ -148,11 +149,11 @@ __global__ __launch_bounds__(TPB) void prep_row_scan_kernel(uint32_t* hist, uint
 
 // one workgroup: bin starts (exclusive scan of the bin totals), the partition-2 chunk list
 // (chunk_base[s] .. chunk_base[s+1]: chunks of bin s; seg_of_chunk[g] = s), bstart[NB] = #entries
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_bins_kernel(const uint32_t* bin_total, uint32_t* bin_start,
                                                         uint32_t* chunk_base, uint32_t* seg_of_chunk,
                                                         uint32_t* nchunk2, uint32_t* bstart_top) {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   side_priority();
   __shared__ uint32_t sh[TPB];
   uint32_t size_carry = 0, chunk_carry = 0;
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(TPB) void prep_bins_kernel(const uint32_t* bin_tota
 }
 
 // entry = low bucket bits << 32 | sign << 31 | table index (window * srs_n + i)
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scalars, uint32_t n, uint32_t srs_n,
                                                             uint32_t nchunk, const uint32_t* hist1,
                                                             const uint32_t* bin_start, uint64_t* ent) {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   side_priority();
   __shared__ uint32_t cur[P::NBIN];
   const uint32_t chunk = blockIdx.x;
@@ -229,11 +230,11 @@ __device__ __forceinline__ Chunk2 chunk2_of(uint32_t g, const uint32_t* bin_star
 }
 
 // hist2[chunk][bucket-in-bin]
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_count2_kernel(const uint64_t* ent, const uint32_t* bin_start,
                                                           const uint32_t* chunk_base, const uint32_t* seg_of_chunk,
                                                           const uint32_t* nchunk2, uint32_t* hist2) {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   side_priority();
   const uint32_t g = blockIdx.x;
   if (g >= *nchunk2) return;
@@ -248,12 +249,12 @@ __global__ __launch_bounds__(TPB) void prep_count2_kernel(const uint64_t* ent, c
 
 // one workgroup per bin: hist2[chunk][b] -> entries of bucket b in earlier chunks of the bin;
 // bstart[bin * BPB + b] = first sorted entry of the bucket
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_scan2_kernel(uint32_t* hist2, const uint32_t* bin_start,
                                                          const uint32_t* chunk_base, uint32_t* bstart) {
-  using P = PW<WB>;
-  constexpr uint32_t PER = P::BPB / TPB;
-  side_priority();
+  using P = PW<WB, LOBV>;
+  constexpr uint32_t PER = P::BPB >= TPB ? P::BPB / TPB : 1;     // buckets a thread owns in the scan (threads beyond
+  side_priority();                                                //   the bin's buckets own none)
   __shared__ uint32_t tot[P::BPB];
   __shared__ uint32_t sh[TPB];
   const uint32_t s = blockIdx.x;
@@ -269,24 +270,27 @@ __global__ __launch_bounds__(TPB) void prep_scan2_kernel(uint32_t* hist2, const 
     tot[b] = run;
   }
   __syncthreads();
+  const bool own = threadIdx.x * PER < P::BPB;
   uint32_t mine = 0;
 #pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) mine += tot[threadIdx.x * PER + q];
+  for (uint32_t q = 0; q < PER; ++q) mine += own ? tot[threadIdx.x * PER + q] : 0u;
   const uint32_t incl = block_inclusive_scan(mine, sh);
   uint32_t run = bin_start[s] + incl - mine;
+  if (own) {
 #pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) {
-    bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = run;
-    run += tot[threadIdx.x * PER + q];
+    for (uint32_t q = 0; q < PER; ++q) {
+      bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = run;
+      run += tot[threadIdx.x * PER + q];
+    }
   }
 }
 
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_scatter2_kernel(const uint64_t* ent, const uint32_t* bin_start,
                                                             const uint32_t* chunk_base, const uint32_t* seg_of_chunk,
                                                             const uint32_t* nchunk2, const uint32_t* hist2,
                                                             const uint32_t* bstart, uint32_t* vals) {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   side_priority();
   const uint32_t g = blockIdx.x;
   if (g >= *nchunk2) return;
@@ -306,13 +310,12 @@ __global__ __launch_bounds__(TPB) void prep_scatter2_kernel(const uint64_t* ent,
 // entries in registers, LDS histogram over the bin's buckets, exclusive scan -> bstart[], ranks by LDS atomics, table
 // indices staged in LDS at their final offset inside the bin, then one contiguous copy to vals[bin_start ..).
 // Reads every entry once and writes each output byte once, in full lines.
-template <int WB>
+template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_binsort_kernel(const uint64_t* ent, const uint32_t* bin_start,
                                                            uint32_t* bstart, uint32_t* vals) {
-  using P = PW<WB>;
-  constexpr uint32_t PER = P::BPB / TPB;
+  using P = PW<WB, LOBV>;
+  constexpr uint32_t PER = P::BPB >= TPB ? P::BPB / TPB : 1;   // buckets a thread owns in the scan
   constexpr uint32_t EPT = STAGE_CAP / TPB;               // entries per thread
-  static_assert(PER >= 1, "one thread owns PER consecutive buckets in the scan");
   static_assert(STAGE_CAP % TPB == 0, "the stage is a whole number of entries per thread");
   side_priority();
   __shared__ uint32_t cur[P::BPB];
@@ -334,17 +337,20 @@ __global__ __launch_bounds__(TPB) void prep_binsort_kernel(const uint64_t* ent, 
   for (uint32_t q = 0; q < EPT; ++q)
     if ((uint32_t)(mine_e[q] >> 32) < P::BPB) atomicAdd(&cur[(uint32_t)(mine_e[q] >> 32)], 1u);
   __syncthreads();
+  const bool own = threadIdx.x * PER < P::BPB;            // (a bin of fewer than TPB buckets: the other threads own none)
   uint32_t mine = 0;
 #pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) mine += cur[threadIdx.x * PER + q];
+  for (uint32_t q = 0; q < PER; ++q) mine += own ? cur[threadIdx.x * PER + q] : 0u;
   const uint32_t incl = block_inclusive_scan(mine, sh);
   uint32_t run = incl - mine;
+  if (own) {
 #pragma unroll
-  for (uint32_t q = 0; q < PER; ++q) {
-    const uint32_t cnt = cur[threadIdx.x * PER + q];
-    bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = e0 + run;
-    cur[threadIdx.x * PER + q] = run;                     // becomes the running rank inside the bin
-    run += cnt;
+    for (uint32_t q = 0; q < PER; ++q) {
+      const uint32_t cnt = cur[threadIdx.x * PER + q];
+      bstart[(size_t)s * P::BPB + threadIdx.x * PER + q] = e0 + run;
+      cur[threadIdx.x * PER + q] = run;                   // becomes the running rank inside the bin
+      run += cnt;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -457,9 +463,9 @@ __global__ __launch_bounds__(TPB) void prep_chunk_rank_kernel(const uint32_t* sl
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <int WB>
+template <int WB, int LOBV>
 struct Layout {
-  using P = PW<WB>;
+  using P = PW<WB, LOBV>;
   uint32_t m, nchunk1, nchunk2_max, nchunkl;
   size_t off_ent, off_hist1, off_bin_total, off_bin_start, off_chunk_base, off_seg_of_chunk, off_nchunk2, off_hist2,
       off_histl, off_class_total, off_class_start, off_ns, total;
@@ -486,12 +492,12 @@ struct Layout {
   }
 };
 
-template <int WB>
+template <int WB, int LOBV>
 int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n, uint32_t seg,
                    void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
                    uint32_t* chunk_counter, uint32_t* chunk_rank, uint32_t nchunk_max) {
-  using P = PW<WB>;
-  const Layout<WB> L(n);
+  using P = PW<WB, LOBV>;
+  const Layout<WB, LOBV> L(n);
   char* w = static_cast<char*>(ws);
   auto* ent = reinterpret_cast<uint64_t*>(w + L.off_ent);
   auto* hist1 = reinterpret_cast<uint32_t*>(w + L.off_hist1);
@@ -507,21 +513,21 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
   auto* ns = reinterpret_cast<uint32_t*>(w + L.off_ns);
   {
     ProfScope ps(c, "msm_partition1", sp);
-    hipLaunchKernelGGL(prep_count1_kernel<WB>, dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, L.nchunk1, hist1);
+    hipLaunchKernelGGL((prep_count1_kernel<WB, LOBV>), dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, L.nchunk1, hist1);
     hipLaunchKernelGGL(prep_row_scan_kernel, dim3(P::NBIN), dim3(TPB), 0, sp, hist1, L.nchunk1, bin_total);
-    hipLaunchKernelGGL(prep_bins_kernel<WB>, dim3(1), dim3(TPB), 0, sp, bin_total, bin_start, chunk_base, seg_of_chunk,
+    hipLaunchKernelGGL((prep_bins_kernel<WB, LOBV>), dim3(1), dim3(TPB), 0, sp, bin_total, bin_start, chunk_base, seg_of_chunk,
                        nchunk2, bstart + P::NB);
-    hipLaunchKernelGGL(prep_scatter1_kernel<WB>, dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, srs_n, L.nchunk1,
+    hipLaunchKernelGGL((prep_scatter1_kernel<WB, LOBV>), dim3(L.nchunk1), dim3(TPB), 0, sp, d_scalars, n, srs_n, L.nchunk1,
                        hist1, bin_start, ent);
   }
   KZG_HIP(c, hipGetLastError());
   {
     ProfScope ps(c, "msm_partition2", sp);
-    hipLaunchKernelGGL(prep_binsort_kernel<WB>, dim3(P::NBIN), dim3(TPB), 0, sp, ent, bin_start, bstart, vals);
-    hipLaunchKernelGGL(prep_count2_kernel<WB>, dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
+    hipLaunchKernelGGL((prep_binsort_kernel<WB, LOBV>), dim3(P::NBIN), dim3(TPB), 0, sp, ent, bin_start, bstart, vals);
+    hipLaunchKernelGGL((prep_count2_kernel<WB, LOBV>), dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
                        seg_of_chunk, nchunk2, hist2);
-    hipLaunchKernelGGL(prep_scan2_kernel<WB>, dim3(P::NBIN), dim3(TPB), 0, sp, hist2, bin_start, chunk_base, bstart);
-    hipLaunchKernelGGL(prep_scatter2_kernel<WB>, dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
+    hipLaunchKernelGGL((prep_scan2_kernel<WB, LOBV>), dim3(P::NBIN), dim3(TPB), 0, sp, hist2, bin_start, chunk_base, bstart);
+    hipLaunchKernelGGL((prep_scatter2_kernel<WB, LOBV>), dim3(L.nchunk2_max), dim3(TPB), 0, sp, ent, bin_start, chunk_base,
                        seg_of_chunk, nchunk2, hist2, bstart, vals);
   }
   KZG_HIP(c, hipGetLastError());
@@ -546,17 +552,37 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
 
 }  // namespace
 
+// Bucket bits per bin for an n-scalar commit: as many bins as keep a bin of uniform scalars (n * windows / bins entries)
+// within the sort stage, up to 8192 (the partition-1 histograms of a workgroup live in LDS: 32 KiB at 8192 bins).
+static int lob_for(uint32_t n, int win_bits) {
+  if (win_bits != 20) return 8;
+  const uint64_t m = (uint64_t)n * PW<20>::NWIN;
+  for (int lob = 8; lob > 6; --lob)
+    if (m / (PW<20>::NB >> lob) + 4 * 82 <= STAGE_CAP) return lob;     // mean + 4 sigma of the 2^20 case as margin
+  return m / (PW<20>::NB >> 8) <= STAGE_CAP ? 8 : 6;
+}
+
 size_t msm_prep_workspace_bytes(uint32_t n, int win_bits) {
-  return win_bits == 20 ? Layout<20>(n).total : Layout<16>(n).total;
+  if (win_bits != 20) return Layout<16, 8>(n).total;
+  switch (lob_for(n, win_bits)) {
+    case 8: return Layout<20, 8>(n).total;
+    case 7: return Layout<20, 7>(n).total;
+    default: return Layout<20, 6>(n).total;
+  }
 }
 
 int msm_prep_enqueue(Ctx* c, hipStream_t sp, int win_bits, const uint32_t* d_scalars, uint32_t n, uint32_t srs_n,
                      uint32_t seg, void* ws, uint32_t* vals, uint32_t* bstart, uint32_t* order, uint32_t* slice_off,
                      uint32_t* chunk_counter, uint32_t* chunk_rank, uint32_t nchunk_max) {
-  return win_bits == 20 ? prep_enqueue_t<20>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off,
-                                             chunk_counter, chunk_rank, nchunk_max)
-                        : prep_enqueue_t<16>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off,
-                                             chunk_counter, chunk_rank, nchunk_max);
+#define KZG_PREP_GO(WBV, LOBV) prep_enqueue_t<WBV, LOBV>(c, sp, d_scalars, n, srs_n, seg, ws, vals, bstart, order, slice_off, \
+                                                        chunk_counter, chunk_rank, nchunk_max)
+  if (win_bits != 20) return KZG_PREP_GO(16, 8);
+  switch (lob_for(n, win_bits)) {
+    case 8: return KZG_PREP_GO(20, 8);
+    case 7: return KZG_PREP_GO(20, 7);
+    default: return KZG_PREP_GO(20, 6);
+  }
+#undef KZG_PREP_GO
 }
 
 }  // namespace kzg

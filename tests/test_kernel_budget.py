@@ -59,5 +59,7 @@ def test_prep_kernels_are_small(kernels):
         # accumulate workgroups of a CU leave; the partition-1 histograms hold 2048 bins (8 KiB)
         # (and its threads keep the bin's entries in registers between the two passes: 2 x 28 VGPRs; two accumulate
         # waves leave 512 - 2 x 153 registers of a SIMD, so such a wave still fits twice)
-        cap, regs = (31 * 1024, 96) if "binsort" in name else (9 * 1024, 64)
+        # the partition-1 histograms of the variants for 2^21 / 2^22 scalars hold 4096 / 8192 bins (16 / 32 KiB)
+        cap, regs = (31 * 1024, 96) if "binsort" in name else \
+                    (33 * 1024, 64) if ("prep_count1" in name or "prep_scatter1" in name) else (9 * 1024, 64)
         assert vgpr <= regs and lds <= cap and scratch == 0, name

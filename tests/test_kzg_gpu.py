@@ -687,3 +687,30 @@ def test_bins_at_the_edge_of_the_sort_stage(native, kzgs, key_log):
     want = O.normalize(O.commit_trapdoor([(r - c) % r for c in coeffs], tau, cv), cv)
     assert inf[0] == 0 and got == want
     srs.close()
+
+
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_commit_at_the_bin_counts_of_larger_polynomials(native, kzgs, log_n):
+    """Partition 1 takes 4096 / 8192 bins for up to 2^21 / 2^22 scalars (msm_prep.hip, lob_for), so that a bin still fits
+    the sort stage: trapdoor identity for uniform scalars over the whole range and for a skewed mix, at 2^21 + 3
+    (what a rank of the 8-way config-4 job commits) and 2^22."""
+    cv = O.BLS12_381
+    r = cv.r
+    ctx = native.get_context("bls12_381")
+    n = (1 << log_n) + (3 if log_n == 21 else 0)
+    tau = 0x2468ace13579 % r
+    srs = ctx.srs_generate(native.int_to_words(tau), n)
+    rs = np.random.RandomState(log_n)
+    raw = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2)
+    raw += rs.randint(0, 2, size=(n, 4)).astype(np.uint64)
+    raw[:, 3] %= np.uint64(r >> 192)
+    for variant in ("uniform", "skewed"):
+        if variant == "skewed":
+            raw[: n // 4] = 0
+            raw[n // 4: n // 2, 1:] = 0                                   # one-limb scalars: the low windows only
+            raw[n // 2: n // 2 + 50000] = raw[n // 2]                     # one value 50,000 times: heavy buckets
+        coeffs = native.limbs_to_ints(raw)
+        xy, inf = ctx.commit(srs, raw.reshape(1, n, 4), [n], n)
+        got = tuple(native.limbs_to_ints(xy.reshape(2, 6)))
+        assert inf[0] == 0 and got == O.normalize(O.commit_trapdoor(coeffs, tau, cv), cv), (log_n, variant)
+    srs.close()

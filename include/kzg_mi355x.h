@@ -74,6 +74,12 @@ const char* kzg_last_error(const kzg_ctx* ctx);
 int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream);
 /* Block until everything enqueued on the context's stream has finished. */
 int kzg_ctx_synchronize(kzg_ctx* ctx);
+/* Fix a choice the library otherwise makes from what is resident on the GPU (tests and A/B timing; results never
+ * depend on it).  value 0 restores the library's choice.  Keys:
+ *   "ntt_tile_log"       log2 of the transform's LDS tile, 8..12 (default: 11 alone, 10 beside an accumulate kernel)
+ *   "open_tile_threads"  threads per tile of the opening's scan, 128 | 256 (default: 256 alone, 128 beside one)
+ *   "open_direct_tiles"  tile count up to which every tile sums all tile aggregates above it (default 1024) */
+int kzg_ctx_set_tuning(kzg_ctx* ctx, const char* key, int64_t value);
 
 /* ---- NTT: replaces fft_ff (fft_ff.py:3-37) and ifft_ff (fft_ff.py:39-58) -------------
  * data: n = 2^log_n elements of Fr, natural order in and out, transformed in place.
@@ -190,7 +196,8 @@ int kzg_open_device_async(kzg_ctx* ctx, const kzg_srs* srs, const void* d_polys,
  * shard.  kzg_open_shard_begin combines the slices (sum xi^(i+1) p_i) and returns the slice
  * polynomial's value H_g = sum_j c_(lo_g+j) z^j.  The ranks exchange the H_g (one field element
  * each); rank g's carry is S_(hi_g) = sum_(g' > g) H_g' * z^(lo_g' - hi_g).  kzg_open_shard_finish
- * appends the carry as one extra top coefficient, scans, and commits the quotient slice:
+ * lets the carry enter the scan above the slice's top coefficient and commits the quotient slice
+ * (it continues from what _begin left on the device: no other open on this context in between):
  *   first_rank != 0: coefficients S_1 .. S_(hi-1) against key points 0 ..      (eval_out = P(z))
  *   otherwise      : coefficients S_lo .. S_(hi-1) against key points lo-1 ..   -- the caller's shard
  *                    must therefore START at global index lo_g - 1 (kzg_srs_generate_range).
@@ -223,11 +230,13 @@ int kzg_fr_poly_eval(kzg_ctx* ctx, size_t n, const void* d_a, const uint64_t z[4
 /* ---- measurement hooks (bench.py) -----------------------------------------------------------
  * When enabled, the library brackets its kernels with HIP events on the stream each one runs on.
  * Span names: "ntt_pass", "msm_partition1", "msm_partition2", "msm_order", "msm_accumulate",
- * "msm_finalize", "msm_reduce", "open_poly".  kzg_prof_read synchronises the stream and returns
- * the accumulated milliseconds and launch count of one span since the last kzg_prof_reset.
+ * "msm_finalize", "msm_reduce", "open_poly" (ONE span per kzg_open*: combination, scan and division),
+ * "open_shard_poly" (one per kzg_open_shard_begin and one per _finish).  kzg_prof_read synchronises the
+ * stream and returns the accumulated milliseconds and span count of one name since the last kzg_prof_reset.
  * Two names are not spans: "msm_accumulate_shader_mhz" and "ntt_pass_shader_mhz" return (in *total_ms) the shader
  * clock in MHz the accumulate / NTT kernel ran at since the last reset -- s_memtime over s_memrealtime ticks of its
- * first wave -- and *count = 1 when a launch has reported, 0 otherwise. */
+ * first wave -- and *count = 1 when a launch has reported, 0 otherwise; "ntt_tile_log" returns log2 of the LDS
+ * tile the last two-pass transform took. */
 int kzg_prof_enable(kzg_ctx* ctx, int on);
 int kzg_prof_reset(kzg_ctx* ctx);
 int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* count);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "kzg_fft_ff_any": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_int]),
     "kzg_fft_ff_any_device": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, _vp, ctypes.c_int]),
     "kzg_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "kzg_ctx_set_tuning": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int64]),
     "kzg_ntt": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int]),
     "kzg_ntt_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint32]),
     "kzg_ntt_columns_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
@@ -214,6 +215,11 @@ class Context:
     def synchronize(self):
         self._check(lib().kzg_ctx_synchronize(self._h))
 
+    def set_tuning(self, key, value):
+        """Fix a choice the library otherwise makes from what is resident ("ntt_tile_log", "open_tile_threads",
+        "open_direct_tiles"; 0 = the library's choice).  Results never depend on it."""
+        self._check(lib().kzg_ctx_set_tuning(self._h, key.encode(), int(value)))
+
     # ---- measurement hooks
     def prof_enable(self, on=True):
         self._check(lib().kzg_prof_enable(self._h, int(bool(on))))
@@ -303,9 +309,11 @@ class Context:
         lens_a = np.asarray(lens, dtype=np.uint64)
         _check_out(out_xy, np.uint64, len(lens) * 2 * self.fp_limbs, "out_xy")
         _check_out(out_inf, np.uint8, len(lens), "out_inf")
-        self._inflight.append((srs, out_xy, out_inf))
+        # the library adopts the host pointers only once the work is queued (msm.hip): on an error nothing points
+        # at these arrays, so they are recorded after the call has returned KZG_OK
         self._check(lib().kzg_commit_device_async(self._h, srs._h, _as_vp(d_scalars), _as_vp(lens_a), len(lens),
                                                   stride, _as_vp(out_xy), _as_vp(out_inf)))
+        self._inflight.append((srs, out_xy, out_inf))
 
     def commit_flush(self):
         """Drain the pipeline: every pending result is on the host when this returns (or raises)."""
@@ -334,10 +342,10 @@ class Context:
         _check_out(out_xy, np.uint64, 2 * self.fp_limbs, "out_xy")
         _check_out(out_inf, np.uint8, 1, "out_inf")
         _check_out(eval_out, np.uint64, 4, "eval_out")
-        self._inflight.append((srs, out_xy, out_inf, eval_out))
         self._check(lib().kzg_open_device_async(self._h, srs._h, _as_vp(d_polys), _as_vp(lens_a), len(lens), stride,
                                                 _as_vp(z_words), _as_vp(xi_words), _as_vp(out_xy), _as_vp(out_inf),
                                                 _as_vp(eval_out)))
+        self._inflight.append((srs, out_xy, out_inf, eval_out))
 
     # ---- device vector / polynomial primitives (device pointers, canonical elements)
     def vec_op(self, op, n, d_a, d_b, d_out):

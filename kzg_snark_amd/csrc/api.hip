@@ -111,6 +111,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
   hipFree(c->ntt_scratch.p);
   hipFree(c->io.p);
   hipFree(c->clk_probe);
+  hipFree(c->scan_tmp.p);
   for (auto& b : c->poly_tmp) hipFree(b.p);
   for (auto s : c->aux_streams) hipStreamDestroy(s);
   for (auto e : c->aux_events) hipEventDestroy(e);
@@ -125,22 +126,16 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
   Ctx* c = &ctx->c;
   KZG_HIP(c, hipSetDevice(c->device));
   if (hip_stream) {
-    // What can be checked is checked before the handle is adopted.  HIP offers no validation of a stream handle:
-    // hipStreamQuery (like every other entry point) dereferences it -- a readable buffer that is no stream crashed the
-    // process on ROCm 7.2 (round 3, profiles/r03_stream_query_crash.log).  So: the two documented aliases
-    // (hipStreamLegacy, hipStreamPerThread) are taken as such; any other small integer or misaligned value cannot be
-    // a runtime object and is refused (the class of gpurun_out/r02_crash.log: an alias or enum value passed where a
-    // handle belongs would reach hipEventRecord); a plausible pointer is then asked for its status, which surfaces
-    // whatever the runtime itself detects (a stream of a destroyed context, a sticky device error).
+    // HIP offers no validation of a stream handle: every entry point, hipStreamQuery included, dereferences it (a
+    // readable buffer that is no stream crashed the process on ROCm 7.2, profiles/r03_stream_query_crash.log, and a
+    // query on a capturing stream would invalidate the capture).  So nothing is asked of the runtime here: the two
+    // documented aliases (hipStreamLegacy, hipStreamPerThread) are taken as such, any other small integer or
+    // misaligned value cannot be a runtime object and is refused, and for everything else the caller guarantees a
+    // live hipStream_t of this process.
     const uintptr_t hv = reinterpret_cast<uintptr_t>(hip_stream);
     const bool alias = hip_stream == static_cast<void*>(hipStreamLegacy) || hip_stream == static_cast<void*>(hipStreamPerThread);
     if (!alias && (hv < 65536 || (hv & 7)))
       return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: not a stream handle (small integer or misaligned value)");
-    const hipError_t q = hipStreamQuery(static_cast<hipStream_t>(hip_stream));
-    if (q != hipSuccess && q != hipErrorNotReady) {
-      (void)hipGetLastError();
-      return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_stream: the runtime does not accept this stream", q);
-    }
     if (c->own_stream && c->stream) {
       KZG_HIP(c, hipStreamSynchronize(c->stream));
       KZG_HIP(c, hipStreamDestroy(c->stream));
@@ -152,6 +147,25 @@ int kzg_ctx_set_stream(kzg_ctx* ctx, void* hip_stream) {
   } else if (!c->own_stream) {
     KZG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
+  }
+  return KZG_OK;
+}
+
+int kzg_ctx_set_tuning(kzg_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  const std::string k(key);
+  if (k == "ntt_tile_log") {
+    if (value != 0 && (value < 8 || value > 12)) return set_err(c, KZG_ERR_ARG, "ntt_tile_log: 0 or 8..12");
+    c->tune_ntt_tile_log = (int)value;
+  } else if (k == "open_tile_threads") {
+    if (value != 0 && value != 128 && value != 256) return set_err(c, KZG_ERR_ARG, "open_tile_threads: 0, 128 or 256");
+    c->tune_open_tb = (int)value;
+  } else if (k == "open_direct_tiles") {
+    if (value < 0 || value > (1 << 20)) return set_err(c, KZG_ERR_ARG, "open_direct_tiles: 0 .. 2^20");
+    c->tune_open_direct_max = (int)value;
+  } else {
+    return set_err(c, KZG_ERR_ARG, "kzg_ctx_set_tuning: unknown key");
   }
   return KZG_OK;
 }
@@ -526,6 +540,11 @@ int kzg_prof_read(kzg_ctx* ctx, const char* name, double* total_ms, uint64_t* co
   *total_ms = 0;
   *count = 0;
   const bool acc_clk = std::string(name) == "msm_accumulate_shader_mhz", ntt_clk = std::string(name) == "ntt_pass_shader_mhz";
+  if (std::string(name) == "ntt_tile_log") {   // not a span: log2 of the LDS tile the last transform took
+    *total_ms = (double)c->last_ntt_tile_log;
+    *count = c->last_ntt_tile_log ? 1 : 0;
+    return KZG_OK;
+  }
   if (acc_clk || ntt_clk) {   // not a span: the shader clock (MHz) the kernel's probing wave ran at
     unsigned long long t[4] = {0, 0, 0, 0};
     if (c->clk_probe) KZG_HIP(c, hipMemcpy(t, c->clk_probe, 32, hipMemcpyDeviceToHost));

@@ -59,8 +59,15 @@ struct Ctx {
   uint32_t ntt_lds_attr_set = 0;   // per ntt_pass_kernel instantiation: hipFuncAttributeMaxDynamicSharedMemorySize applies per device
   DevBuf ntt_scratch;     // pass-1 output of two-pass transforms
   DevBuf io;              // staging for the host-pointer entry points
-  DevBuf poly_tmp[4];     // open(): combined polynomial, quotient, scan carries
+  DevBuf poly_tmp[4];     // open(): combined polynomial + suffix values; scratch of the vector primitives
+  DevBuf scan_tmp;        // open(): chunk values, tile aggregates, power tables (kept between the shard calls)
   size_t open_shard_n = 0;                // slice length between kzg_open_shard_begin / _finish
+  uint32_t open_shard_tb = 0;             // tile width the slice's aggregates were formed with
+  // kzg_ctx_set_tuning: 0 = the library's own choice
+  int tune_ntt_tile_log = 0;              // LDS tile of the transform (8..12)
+  int tune_open_tb = 0;                   // threads per tile of the opening's scan (128 | 256)
+  int tune_open_direct_max = 0;           // tiles up to which every tile sums all aggregates above it
+  int last_ntt_tile_log = 0;              // what the last transform used (kzg_prof_read "ntt_tile_log")
   void* msm_work = nullptr;               // MsmWork (msm.hip)
   bool prof_on = false;
   std::vector<ProfSpan> prof;

@@ -432,12 +432,15 @@ int build_domain(Ctx* c, NttDomain& d) {
 // NEXT accumulate kernel starts short of workgroups, whereas a 1024-element tile (36 KiB, 256 threads, one wave of <= 122
 // VGPRs per SIMD) fits beside them.  Round 3, same box, alternating, bench.py at B = 4: 464.6 / 460.9 commits/s with
 // 1024-element tiles against 432.3 / 439.2 (the NTT alone: 100.4 vs 99.0 us, HBM traffic per transform unchanged at
-// 2.04x algorithmic) -- so the tile follows what is resident.  KZG_NTT_TILE_LOG = 9 .. 12 fixes it (experiments).
+// 2.04x algorithmic) -- so the tile follows what is resident.  kzg_ctx_set_tuning(ctx, "ntt_tile_log", 8 .. 12) or
+// KZG_NTT_TILE_LOG fixes it (tests, experiments); kzg_prof_read(ctx, "ntt_tile_log") tells what the last transform took.
 constexpr int TILE_LOG_BESIDE_MSM = 10;
 static uint32_t tile_log_pref(Ctx* c) {
   static const int fixed = [] { const char* e = getenv("KZG_NTT_TILE_LOG"); return e ? atoi(e) : 0; }();
-  const int x = fixed ? fixed : (msm_accumulate_in_flight(c) ? TILE_LOG_BESIDE_MSM : TILE_LOG_2WG);
-  return (uint32_t)std::min(std::max(x, 8), TILE_LOG);
+  const int forced = c->tune_ntt_tile_log ? c->tune_ntt_tile_log : fixed;     // kzg_ctx_set_tuning("ntt_tile_log") first
+  const int x = forced ? forced : (msm_accumulate_in_flight(c) ? TILE_LOG_BESIDE_MSM : TILE_LOG_2WG);
+  c->last_ntt_tile_log = std::min(std::max(x, 8), TILE_LOG);
+  return (uint32_t)c->last_ntt_tile_log;
 }
 
 template <class F>

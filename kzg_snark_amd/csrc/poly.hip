@@ -5,13 +5,9 @@
 //
 // Division by (X - z) is synthetic division: with S_j = sum_{i>=j} c_i z^(i-j)
 // (suffix Horner values, S_j = c_j + z*S_{j+1}) the quotient is q_{j-1} = S_j for
-// j >= 1 and combined(z) = S_0.  The first-order recurrence is evaluated in
-// parallel by chunking: chunks of SC coefficients are collapsed bottom-up into
-// one value each (a polynomial in z^SC of 1/SC the length; repeated until <= SC
-// values remain), the short top level is solved directly, and the suffix values
-// are pushed back down, each thread re-walking its chunk from the carry above.
-// Cost: ~2 Montgomery multiplications per coefficient, all data HBM-streamed
-// twice.  The MSM of the quotient (msm.hip) dominates open() by far.
+// j >= 1 and combined(z) = S_0.  The recurrence is evaluated in two tile passes (below,
+// "The opening's scan as TWO tile passes"); the level-by-level chunk collapse of rounds 1-3
+// survives in kzg_fr_poly_eval.  The MSM of the quotient (msm.hip) dominates open() by far.
 // These kernels are bound by dependent Horner chains and by memory latency, not by instruction issue: the chain pin of
 // field.h (an asm volatile per multiply-add) would only keep the scheduler from hoisting the next loads.
 #define KZG_NO_CHAIN_PIN 1
@@ -26,13 +22,9 @@ namespace kzg {
 namespace {
 
 constexpr uint32_t LC = 32;       // elements per thread of the vector primitives (batch inversion, powers, prefix product)
-// Chunk of the suffix-Horner scans (open, poly_eval): their cost is the DEPENDENT chain of SC multiply-adds per
-// thread, not bandwidth -- measured at 2^20, k = 6: 151 us with chunks of 32, 129 with 16, 114 with 8 (more, shorter
-// levels; the batch inversion above wants the opposite, hence two constants).
-#ifndef KZG_POLY_SC_LOG
-#define KZG_POLY_SC_LOG 3
-#endif
-constexpr uint32_t SC_LOG = KZG_POLY_SC_LOG;
+// Chunk of the suffix-Horner scans (open, poly_eval): what one thread walks serially, and the group of lanes whose
+// products one DPP sum collapses (8 limbs of 29 bits stay below 2^32).
+constexpr uint32_t SC_LOG = 3;
 constexpr uint32_t SC = 1u << SC_LOG;
 constexpr uint32_t MAXK = 64;     // polynomials per open()
 
@@ -117,52 +109,6 @@ __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
   store_words<F>(out + (size_t)t * 8, acc);
 }
 
-// The same with the bottom level of the evaluation fused in (round 3): beside comb[t] the workgroup also leaves
-// h1[c] = sum_{j < SC} comb[c*SC + j] * z^j for its 256 / SC chunks, so the scan does not read the combination a second
-// time for that.  Each thread multiplies its coefficient by z^(t mod SC) (table in LDS), the SC products of a chunk are
-// added lazily by its first lane (SC * 2p stays far below 2^261 and SC limbs of 29 bits below 2^32) and reduced once.
-struct ZPowArgs {
-  uint32_t l[SC * FRN];      // z^0 .. z^(SC-1), Montgomery form
-};
-template <class F>
-__global__ __launch_bounds__(256) void lincomb_eval_kernel(LincombArgs a, ZPowArgs zp, uint32_t* out, uint32_t n,
-                                                           uint32_t* h1) {
-  using Fd = Field<F>;
-  static_assert(F::N == FRN && 256 % SC == 0 && SC <= 8, "chunk layout of the fused evaluation");
-  __shared__ uint32_t zs[SC * FRN];
-  __shared__ uint32_t es[256 * FRN];                         // stride 9 words: conflict-free across consecutive lanes
-  const uint32_t tid = threadIdx.x;
-  const uint32_t t = blockIdx.x * 256 + tid;
-  if (tid < SC * FRN) zs[tid] = zp.l[tid];
-  Fe<F> acc = Fd::zero();
-  if (t < n) {
-    for (uint32_t i0 = 0; i0 < a.k; i0 += DOT_G) {
-      const uint32_t cnt = min(DOT_G, a.k - i0);
-      Fe<F> c[DOT_G], x[DOT_G];
-#pragma unroll
-      for (uint32_t g = 0; g < DOT_G; ++g) {
-        const uint32_t i = i0 + g;
-        const bool on = g < cnt && t < a.lens[i];
-        c[g] = on ? load_words<F>(a.polys + (a.stride * i + t) * 8) : Fd::zero();
-        x[g] = load_limbs<F>(a.xipow + (g < cnt ? i : i0) * F::N);
-      }
-      const Fe<F> part = dot_upto<F>(cnt, c, x);
-      acc = i0 ? Fd::add(acc, part) : part;
-    }
-    store_words<F>(out + (size_t)t * 8, acc);
-  }
-  __syncthreads();
-  const Fe<F> e = Fd::mul(acc, load_limbs<F>(zs + (tid & (SC - 1)) * F::N));      // 0 beyond the polynomial's end
-  store_limbs<F>(es + tid * F::N, e);
-  __syncthreads();
-  if ((tid & (SC - 1)) == 0 && t < n) {
-    Fe<F> sum = e;
-#pragma unroll
-    for (uint32_t j = 1; j < SC; ++j) sum = Fd::add_lazy(sum, load_limbs<F>(es + (tid + j) * F::N));
-    store_limbs<F>(h1 + (size_t)(t / SC) * F::N, Fd::reduce_wide(Fd::carry(sum)));
-  }
-}
-
 // bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*SC)
 template <class F, bool WORDS_IN>
 __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* h) {
@@ -180,46 +126,6 @@ __global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, ui
   store_limbs<F>(h + (size_t)t * F::N, acc);
 }
 
-// top level (m <= SC): S[j] = c_j + z*S[j+1], S[m] = 0; one thread
-template <class F>
-__global__ void top_suffix_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* S) {
-  using Fd = Field<F>;
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const Fe<F> z = load_limbs<F>(zpow.l);
-  Fe<F> acc = Fd::zero();
-  store_limbs<F>(S + (size_t)m * F::N, acc);
-  for (uint32_t j = m; j-- > 0;) {
-    acc = Fd::add(load_limbs<F>(in + (size_t)j * F::N), Fd::mul(acc, z));
-    store_limbs<F>(S + (size_t)j * F::N, acc);
-  }
-}
-
-// top-down: S[j] for j in chunk t, starting from the carry S_up[t+1].
-// FINAL: input is the coefficient array (words); writes quotient q[j-1] = S_j and eval = S_0.
-template <class F, bool FINAL>
-__global__ void chunk_fill_kernel(const uint32_t* in, uint32_t m, FrArg zpow, const uint32_t* S_up,
-                                  uint32_t* S_out, uint32_t* quot, uint32_t* eval_out) {
-  using Fd = Field<F>;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j0 = t * SC;
-  if (j0 >= m) return;
-  const uint32_t j1 = min(j0 + SC, m);
-  const Fe<F> z = load_limbs<F>(zpow.l);
-  Fe<F> acc = load_limbs<F>(S_up + (size_t)(t + 1) * F::N);
-  if (!FINAL && t == 0 && j1 == m) { /* single chunk: nothing above */ }
-  for (uint32_t j = j1; j-- > j0;) {
-    const Fe<F> c = FINAL ? load_words<F>(in + (size_t)j * 8) : load_limbs<F>(in + (size_t)j * F::N);
-    acc = Fd::add(c, Fd::mul(acc, z));
-    if (FINAL) {
-      if (j >= 1) store_words<F>(quot + (size_t)(j - 1) * 8, acc);
-      else store_words<F>(eval_out, acc);
-    } else {
-      store_limbs<F>(S_out + (size_t)j * F::N, acc);
-    }
-  }
-  if (!FINAL && j1 == m) store_limbs<F>(S_out + (size_t)m * F::N, Fd::zero());
-}
-
 __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size_t to_elem, uint32_t* flag) {
   const size_t i = from_elem + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= to_elem) return;
@@ -228,32 +134,250 @@ __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size
   if (acc) atomicOr(flag, 1u);
 }
 
-// The last fill (coefficients in, quotient out) through LDS (round 3): a workgroup loads its FILL_EPB consecutive
-// coefficients with fully coalesced 16-byte accesses, every thread walks its SC-element chunk in LDS (one pad quad per
-// chunk spreads the 256-byte lane stride over the banks), and the suffix values leave coalesced again -- S[j] goes to
-// S_base + j (S_0 = the evaluation, S_j = quotient coefficient j-1: one contiguous vector, see the buffer layout).
-// The round-2 kernel read and wrote 32-byte elements at 256-byte lane strides: 1.7x / 1.55x the bytes (r03_open_pmc.csv).
-constexpr uint32_t FILL_TB = 128, FILL_EPB = FILL_TB * SC;
+// =====================================================================================
+// The opening's scan as TWO tile passes (round 4; rounds 1-3 collapsed chunks of 8 level by level: thirteen launches
+// for a 2^20 opening, eleven of them 7-9 us dependent chains on a handful of waves).
+//
+// A workgroup of TB threads owns a TILE of T = 8 TB consecutive coefficients c_(bT) .. c_(bT+T-1) (thread q owns the
+// chunk of 8 at local offset 8q).  With z != 0 the suffix values S_j = sum_(i >= j) c_i z^(i-j) are plain suffix SUMS of
+// scaled terms, S_j = z^-j sum_(i >= j) c_i z^i, and the scaling is applied hierarchically so that no power table is
+// longer than a tile:
+//
+//   pass 1 (tile_combine_kernel): comb = sum_i xi^(i+1) p_i (kzg.py:148-150), coalesced (thread t takes the local
+//     elements t, t + TB, ..); e = comb * z^(pos mod 8); the 8 products of a chunk are added across 8 adjacent lanes by
+//     DPP (lazily: 8 limbs of 29 bits stay below 2^32) -> h_q = sum_(r<8) c_(8q+r) z^r; g_q = h_q z^(8q); the tile's
+//     aggregate H_b = sum_q g_q = sum_(i<T) c_(bT+i) z^i.  Written: comb (32 B per coefficient), g (36 B per chunk),
+//     H (36 B per tile).  Extra workgroups at the end of the grid build the two tables pass 2 reads: zinv[q] = z^(-8q)
+//     (q <= TB) and W[k] = z^(T(k+1)), from a few generator powers the host passes in the kernel arguments.
+//   pass 2 (tile_fill_kernel): every tile sums the aggregates ABOVE it itself, Q_b = z^T S_((b+1)T) = sum_(k>=0) H_(b+1+k) W[k]
+//     -- one product per tile pair, 1.3 * 10^5 products at 2^20, spread over all workgroups: there is no serial chain
+//     over the tiles and no launch per level; beyond 1024 tiles the aggregates of 64 tiles are first folded into one
+//     (tile_group_kernel) so that a tile never sums more than 63 + ntiles/64 terms.  Inside the tile a wave-wide suffix
+//     sum of the g_q (additions only) gives the carry into chunk q, S_(bT+8(q+1)) = zinv[q+1] (sum_(q'>q) g_q' + Q_b),
+//     and each thread walks its 8 coefficients in LDS from there (S_j = c_j + z S_(j+1)); the suffix values leave
+//     coalesced: S_0 = combined(z), S_j = quotient coefficient j-1 (kzg.py:153-154).
+//
+// Products per coefficient: the combination's k (one reduction, Field::dot) + 1 (e) + 1 (walk) + (2 + 1 + ~1)/8.
+// Traffic: k + 1 reads of 32 B, 2 writes of 32 B per coefficient + 9 B per coefficient of g -> (k+3)/(k+1) of the
+// algorithmic bytes, the floor of a combine-then-scan structure.  z = 0 has no inverse: then S_j = c_j, a copy.
+// =====================================================================================
+constexpr uint32_t SG_LOG = 6, SG = 1u << SG_LOG;      // tiles per group of the two-level aggregate sum
+constexpr uint32_t TILE_MAXK = 16;                     // polynomials per tile_combine launch (more: combined first)
+constexpr uint32_t TILE_GW = 22;                       // generator powers z^(T 2^s) for the W table: 2^22 tiles
+constexpr uint32_t TILE_DIRECT_MAX = 1024;             // up to this many tiles every tile sums all aggregates above it
+
+struct TileLincomb {
+  const uint32_t* polys;
+  uint64_t stride;
+  uint32_t k;
+  uint32_t lens[TILE_MAXK];
+  uint32_t xipow[TILE_MAXK * FRN];    // xi^(i+1), Montgomery form
+};
+struct TileScanArgs {                 // all Montgomery form; 2.5 KB of the 4 KB kernel-argument limit with TileLincomb
+  uint32_t zs[SC * FRN];              // z^r, r < 8
+  uint32_t zq_lo[16 * FRN];           // z^(8c), c < 16         z^(8q) = zq_lo[q & 15] * zq_hi[q >> 4]
+  uint32_t zq_hi[16 * FRN];           // z^(128c), c < 16
+  uint32_t ginv[9 * FRN];             // z^(-8 * 2^s), s <= 8   -> zinv[q], q <= 256
+  uint32_t gw[TILE_GW * FRN];         // z^(T * 2^s)            -> W[k] = z^(T(k+1))
+};
+
+// sum over the 8 lanes of an aligned group (every lane of the group ends with the total): two quad permutes and a
+// half-row mirror, no LDS
+__device__ __forceinline__ uint32_t lane8_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);     // quad_perm:[1,0,3,2]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);     // quad_perm:[2,3,0,1]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);    // row_half_mirror
+  return x;
+}
+// 8 weak-normal values -> their canonical sum (8 * 2p < 2^261, limbs < 2^32), in every lane of the group
 template <class F>
-__global__ __launch_bounds__(FILL_TB) void chunk_fill_final_kernel(const uint32_t* in, uint32_t m, FrArg zpow,
-                                                                    const uint32_t* S_up, uint32_t* S_base) {
+__device__ __forceinline__ Fe<F> lane8_sum_reduced(const Fe<F>& v) {
+  Fe<F> s;
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) s.l[j] = lane8_sum(v.l[j]);
+  return Field<F>::reduce_wide(Field<F>::carry(s));
+}
+// Sum of one weak-normal value per thread over the workgroup (all threads call it); valid in thread 0 only.
+// red: (TB / 8 + TB / 64) elements of LDS.
+template <class F, uint32_t TB>
+__device__ __forceinline__ Fe<F> block_sum(const Fe<F>& v, uint32_t* red) {
   using Fd = Field<F>;
-  __shared__ uint4 st[FILL_EPB * 2 + FILL_TB];
-  const uint32_t tid = threadIdx.x, e0 = blockIdx.x * FILL_EPB;
-  const uint4* gin = reinterpret_cast<const uint4*>(in);
-  for (uint32_t i = tid; i < FILL_EPB * 2; i += FILL_TB) {
-    const uint32_t e = i >> 1;
-    if (e0 + e < m) st[i + (e >> SC_LOG)] = gin[(size_t)(e0 + e) * 2 + (i & 1)];
+  const uint32_t tid = threadIdx.x;
+  const Fe<F> s1 = lane8_sum_reduced<F>(v);
+  if ((tid & 7) == 0) store_limbs<F>(red + (tid >> 3) * F::N, s1);
+  __syncthreads();
+  const Fe<F> x = tid < TB / 8 ? load_limbs<F>(red + tid * F::N) : Fd::zero();
+  const Fe<F> s2 = lane8_sum_reduced<F>(x);
+  if ((tid & 7) == 0 && tid < TB / 8) store_limbs<F>(red + (TB / 8 + (tid >> 3)) * F::N, s2);
+  __syncthreads();
+  Fe<F> r = Fd::zero();
+  if (tid == 0)
+    for (uint32_t u = 0; u < TB / 64; ++u) r = Fd::add(r, load_limbs<F>(red + (TB / 8 + u) * F::N));
+  return r;
+}
+// product of the generators g[s] over the set bits s of e (Montgomery form)
+template <class F>
+__device__ __forceinline__ Fe<F> pow_from_generators(const uint32_t* g, uint32_t e) {
+  Fe<F> p = Field<F>::one();
+  for (uint32_t s = 0; (e >> s) != 0; ++s)
+    if ((e >> s) & 1u) p = Field<F>::mul(p, load_limbs<F>(g + s * F::N));
+  return p;
+}
+
+template <class F, uint32_t TB>
+__global__ __launch_bounds__(TB) void tile_combine_kernel(TileLincomb a, TileScanArgs ts, uint32_t* comb, uint32_t n,
+                                                          uint32_t ntiles, uint32_t* G, uint32_t* H, uint32_t* zinv,
+                                                          uint32_t* W) {
+  using Fd = Field<F>;
+  static_assert(F::N == FRN && SC == 8 && TB % 64 == 0 && TB <= 256, "tile layout");
+  constexpr uint32_t T = TB * SC;
+  __shared__ uint32_t hs[TB * FRN];                         // chunk sums (lazy limbs)
+  __shared__ uint32_t zsh[SC * FRN];
+  __shared__ uint32_t red[(TB / 8 + TB / 64) * FRN];
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= ntiles) {                               // table workgroups: nothing of pass 1 reads these
+    const uint32_t t = (blockIdx.x - ntiles) * TB + tid;
+    if (t <= TB) store_limbs<F>(zinv + (size_t)t * F::N, pow_from_generators<F>(ts.ginv, t));
+    if (t < ntiles) store_limbs<F>(W + (size_t)t * F::N, pow_from_generators<F>(ts.gw, t + 1));
+    return;
+  }
+  const uint32_t b = blockIdx.x, base = b * T;
+  if (tid < SC * FRN) zsh[tid] = ts.zs[tid];
+  __syncthreads();
+  const Fe<F> zr = load_limbs<F>(zsh + (tid & (SC - 1)) * F::N);
+#pragma unroll 1
+  for (uint32_t it = 0; it < SC; ++it) {
+    const uint32_t i = it * TB + tid, t = base + i;
+    Fe<F> acc = Fd::zero();
+    if (t < n) {
+      for (uint32_t i0 = 0; i0 < a.k; i0 += DOT_G) {
+        const uint32_t cnt = min(DOT_G, a.k - i0);
+        Fe<F> c[DOT_G], x[DOT_G];
+#pragma unroll
+        for (uint32_t g = 0; g < DOT_G; ++g) {
+          const uint32_t p = i0 + g;
+          const bool on = g < cnt && t < a.lens[g < cnt ? p : i0];           // shorter polynomials read as zero-padded
+          c[g] = on ? load_words<F>(a.polys + (a.stride * p + t) * 8) : Fd::zero();
+          x[g] = load_limbs<F>(a.xipow + (g < cnt ? p : i0) * F::N);
+        }
+        const Fe<F> part = dot_upto<F>(cnt, c, x);
+        acc = i0 ? Fd::add(acc, part) : part;
+      }
+      store_words<F>(comb + (size_t)t * 8, acc);
+    }
+    const Fe<F> e = Fd::mul(acc, zr);                                         // 0 beyond the end
+    Fe<F> s;
+#pragma unroll
+    for (int j = 0; j < F::N; ++j) s.l[j] = lane8_sum(e.l[j]);
+    if ((tid & 7) == 0) store_limbs<F>(hs + (i >> 3) * F::N, s);
   }
   __syncthreads();
-  const uint32_t t = blockIdx.x * FILL_TB + tid;
-  const uint32_t j0 = t * SC;
-  if (j0 < m) {
-    const uint32_t j1 = min(j0 + SC, m);
-    const Fe<F> z = load_limbs<F>(zpow.l);
-    Fe<F> acc = load_limbs<F>(S_up + (size_t)(t + 1) * F::N);
-    for (uint32_t j = j1; j-- > j0;) {
-      const uint32_t q = (j - e0) * 2 + tid;                 // (j - e0) >> SC_LOG == tid
+  const Fe<F> hq = Fd::reduce_wide(Fd::carry(load_limbs<F>(hs + tid * F::N)));
+  const Fe<F> zq = Fd::mul(load_limbs<F>(ts.zq_lo + (tid & 15) * F::N), load_limbs<F>(ts.zq_hi + (tid >> 4) * F::N));
+  const Fe<F> g = Fd::mul(hq, zq);
+  store_limbs<F>(G + ((size_t)b * TB + tid) * F::N, g);
+  const Fe<F> hb = block_sum<F, TB>(g, red);
+  if (tid == 0) store_limbs<F>(H + (size_t)b * F::N, hb);
+}
+
+// A[s] = sum_(i < 64) H[64 s + i] z^(T i): one wave per group of tiles
+template <class F>
+__global__ __launch_bounds__(64) void tile_group_kernel(const uint32_t* H, const uint32_t* W, uint32_t ntiles,
+                                                        uint32_t* A) {
+  using Fd = Field<F>;
+  static_assert(SG == 64, "one wave per group");
+  const uint32_t s = blockIdx.x, i = threadIdx.x, bt = s * SG + i;
+  Fe<F> v = Fd::zero();
+  if (bt < ntiles) {
+    v = load_limbs<F>(H + (size_t)bt * F::N);
+    if (i) v = Fd::mul(v, load_limbs<F>(W + (size_t)(i - 1) * F::N));
+  }
+  const Fe<F> x = lane8_sum_reduced<F>(v);
+  Fe<F> r = x;
+#pragma unroll 1
+  for (uint32_t u = 1; u < 8; ++u) {
+    Fe<F> t;
+#pragma unroll
+    for (int j = 0; j < F::N; ++j) t.l[j] = (uint32_t)__shfl((int)x.l[j], (int)(u * 8));
+    r = Fd::add(r, t);
+  }
+  if (i == 0) store_limbs<F>(A + (size_t)s * F::N, r);
+}
+
+// Q_b = sum over everything above tile b, each term once: tiles of b's own group, then whole groups (A != null), then
+// the caller's carry as the aggregate of a virtual tile `ntiles` (sharded open).  All threads call; valid in thread 0.
+template <class F, uint32_t TB>
+__device__ __forceinline__ Fe<F> tile_carry_sum(uint32_t b, uint32_t ntiles, const uint32_t* H, const uint32_t* A,
+                                                uint32_t nsuper, const FrArg& hv, uint32_t has_hv, const uint32_t* W,
+                                                uint32_t* red) {
+  using Fd = Field<F>;
+  const uint32_t tid = threadIdx.x;
+  Fe<F> acc = Fd::zero();
+  if (!A) {
+    for (uint32_t bp = b + 1 + tid; bp < ntiles; bp += TB)
+      acc = Fd::add(acc, Fd::mul(load_limbs<F>(H + (size_t)bp * F::N), load_limbs<F>(W + (size_t)(bp - b - 1) * F::N)));
+  } else {
+    const uint32_t s = b >> SG_LOG, gend = min((s + 1) << SG_LOG, ntiles);
+    for (uint32_t bp = b + 1 + tid; bp < gend; bp += TB)
+      acc = Fd::add(acc, Fd::mul(load_limbs<F>(H + (size_t)bp * F::N), load_limbs<F>(W + (size_t)(bp - b - 1) * F::N)));
+    for (uint32_t sp = s + 1 + tid; sp < nsuper; sp += TB)
+      acc = Fd::add(acc, Fd::mul(load_limbs<F>(A + (size_t)sp * F::N),
+                                 load_limbs<F>(W + (size_t)((sp << SG_LOG) - b - 1) * F::N)));
+  }
+  if (has_hv && tid == TB - 1)
+    acc = Fd::add(acc, Fd::mul(load_limbs<F>(hv.l), load_limbs<F>(W + (size_t)(ntiles - b - 1) * F::N)));
+  return block_sum<F, TB>(acc, red);
+}
+
+template <class F, uint32_t TB>
+__global__ __launch_bounds__(TB) void tile_fill_kernel(const uint32_t* comb, uint32_t n, uint32_t ntiles,
+                                                       const uint32_t* G, const uint32_t* H, const uint32_t* A,
+                                                       uint32_t nsuper, FrArg hv, uint32_t has_hv, FrArg zarg,
+                                                       const uint32_t* zinv, const uint32_t* W, uint32_t* S_base) {
+  using Fd = Field<F>;
+  constexpr uint32_t T = TB * SC, NWAVE = TB / 64;
+  __shared__ uint4 st[T * 2 + TB];                          // 32 B per coefficient + one pad quad per chunk
+  __shared__ uint32_t red[(TB / 8 + TB / 64) * FRN];
+  __shared__ uint32_t wsum[NWAVE * FRN];
+  __shared__ uint32_t qsh[FRN];
+  const uint32_t tid = threadIdx.x, b = blockIdx.x, e0 = b * T;
+  const uint4* gin = reinterpret_cast<const uint4*>(comb);
+  for (uint32_t i = tid; i < T * 2; i += TB) {
+    const uint32_t e = i >> 1;
+    if (e0 + e < n) st[i + (e >> SC_LOG)] = gin[(size_t)(e0 + e) * 2 + (i & 1)];
+  }
+  const Fe<F> q0 = tile_carry_sum<F, TB>(b, ntiles, H, A, nsuper, hv, has_hv, W, red);
+  if (tid == 0) store_limbs<F>(qsh, q0);
+  // suffix sums of the tile's scaled chunk values: inclusive inside the wave by shuffles, the waves above from LDS
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  Fe<F> incl = load_limbs<F>(G + ((size_t)b * TB + tid) * F::N);
+#pragma unroll 1
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    Fe<F> t;
+#pragma unroll
+    for (int j = 0; j < F::N; ++j) t.l[j] = (uint32_t)__shfl_down((int)incl.l[j], d);
+    const Fe<F> s = Fd::add(incl, t);
+    incl = Fd::select(lane + d < 64, s, incl);
+  }
+  if (lane == 0) store_limbs<F>(wsum + wave * F::N, incl);
+  Fe<F> ex;                                                 // sum over the chunks after this one
+#pragma unroll
+  for (int j = 0; j < F::N; ++j) {
+    const uint32_t t = (uint32_t)__shfl_down((int)incl.l[j], 1);
+    ex.l[j] = lane == 63 ? 0u : t;
+  }
+  __syncthreads();                                          // st, qsh, wsum complete
+  for (uint32_t w = wave + 1; w < NWAVE; ++w) ex = Fd::add(ex, load_limbs<F>(wsum + w * F::N));
+  Fe<F> acc = Fd::mul(Fd::add(ex, load_limbs<F>(qsh)), load_limbs<F>(zinv + (size_t)(tid + 1) * F::N));
+  const uint32_t j0 = e0 + tid * SC;
+  if (j0 < n) {
+    const Fe<F> z = load_limbs<F>(zarg.l);
+    for (uint32_t j = j0 + SC; j-- > j0;) {
+      if (j >= n) {                                         // the chunk that holds the end: zero coefficients above it
+        if (has_hv) acc = Fd::mul(acc, z);
+        continue;
+      }
+      const uint32_t q = (j - e0) * 2 + tid;                // (j - e0) >> SC_LOG == tid
       const uint4 lo = st[q], hi = st[q + 1];
       const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
       acc = Fd::add(Fd::from_words(w), Fd::mul(acc, z));
@@ -265,42 +389,99 @@ __global__ __launch_bounds__(FILL_TB) void chunk_fill_final_kernel(const uint32_
   }
   __syncthreads();
   uint4* gout = reinterpret_cast<uint4*>(S_base);
-  for (uint32_t i = tid; i < FILL_EPB * 2; i += FILL_TB) {
+  for (uint32_t i = tid; i < T * 2; i += TB) {
     const uint32_t e = i >> 1;
-    if (e0 + e < m) gout[(size_t)(e0 + e) * 2 + (i & 1)] = st[i + (e >> SC_LOG)];
+    if (e0 + e < n) gout[(size_t)(e0 + e) * 2 + (i & 1)] = st[i + (e >> SC_LOG)];
   }
+}
+
+// S_0 alone (the slice evaluation of a sharded open): H_0 + sum_k H_(1+k) W[k]
+template <class F, uint32_t TB>
+__global__ __launch_bounds__(TB) void tile_eval_kernel(uint32_t ntiles, const uint32_t* H, const uint32_t* A,
+                                                       uint32_t nsuper, const uint32_t* W, uint32_t* out_words) {
+  using Fd = Field<F>;
+  __shared__ uint32_t red[(TB / 8 + TB / 64) * FRN];
+  FrArg none{};
+  const Fe<F> q0 = tile_carry_sum<F, TB>(0, ntiles, H, A, nsuper, none, 0, W, red);
+  if (threadIdx.x == 0) store_words<F>(out_words, Fd::add(q0, load_limbs<F>(H)));
 }
 
 // Buffer layout of poly_tmp[0] (canonical words, 8 per element), cap = n + 1:
-//   comb[0 .. cap)   combined polynomial (+ one optional appended top coefficient)
+//   comb[0 .. cap)   combined polynomial
 //   eval             S_0
 //   quot[0 .. cap)   S_1, S_2, ...        => [eval, quot...] is the contiguous vector S_0, S_1, ...
-// total entries of the levels above the coefficients (h_1 .. h_(nl-1)) for n coefficients
-static size_t scan_level_entries(size_t n) {
-  size_t total = 0;
-  for (size_t m = n; m > SC;) { m = (m + SC - 1) / SC; total += m; }
-  return total;
+// scan_tmp: g (9 words per chunk), H (per tile, + 1), A (per group of 64 tiles), zinv (TB + 1), W (per tile).
+template <class F>
+struct TilePlan {
+  uint32_t tb = 0, ntiles = 0, ntab = 0, nsuper = 0;        // nsuper = 0: every tile sums all aggregates above it
+  TileScanArgs ts;
+  FrArg z;                                                    // Montgomery form
+  Fe<F> z_inv;                                                // Montgomery form
+  uint32_t *G = nullptr, *H = nullptr, *A = nullptr, *zinv = nullptr, *W = nullptr;
+};
+
+template <class F>
+static FrArg fr_arg(const Fe<F>& v) {
+  FrArg a;
+  memcpy(a.l, v.l, F::N * 4);
+  return a;
+}
+static bool words_are_zero(const uint32_t* w) {
+  uint32_t acc = 0;
+  for (int i = 0; i < 8; ++i) acc |= w[i];
+  return acc == 0;
 }
 
-// z_words given: the bottom level of the evaluation at z is fused into the combination (h_1 lands at the start of
-// poly_tmp[2], where open_scan_t(.., h1_ready = true) expects it).
+// Tile width: 256 threads (2048 coefficients, 65 KiB of LDS in the fill) when the GPU is the opening's; 128 threads
+// (33 KiB) while an accumulate kernel of the commit pipeline holds 114 of a CU's 160 KiB, so that the fill still gets
+// a workgroup onto every CU (the transform makes the same choice, ntt.hip).  c->tune_open_tb fixes it (tests).
+static uint32_t open_tile_threads(Ctx* c) {
+  if (c->tune_open_tb == 128 || c->tune_open_tb == 256) return (uint32_t)c->tune_open_tb;
+  return msm_accumulate_in_flight(c) ? 128u : 256u;
+}
+
 template <class F>
-int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
-                   const uint32_t* xi_words, size_t* n_out, const uint32_t* z_words = nullptr) {
+int tile_plan(Ctx* c, size_t n, const uint32_t* z_words, uint32_t tb, TilePlan<F>* p) {
   using Fd = Field<F>;
-  if (k > MAXK) return set_err(c, KZG_ERR_ARG, "kzg_open: more than 64 polynomials");
-  size_t n = 0;
-  for (size_t i = 0; i < k; ++i) {
-    if (lens[i] > stride) return set_err(c, KZG_ERR_ARG, "kzg_open: lens[i] > stride");
-    n = std::max(n, lens[i]);
-  }
-  *n_out = n;
-  if (n == 0) return KZG_OK;
-  if (n >= (1ull << 31) - 1) return set_err(c, KZG_ERR_ARG, "kzg_open: polynomial too long");
-  int rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * (n + 1) + 1) * 32))) return rc;
-  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
-  ProfScope ps(c, "open_poly");
+  const uint32_t T = tb * SC;
+  p->tb = tb;
+  p->ntiles = (uint32_t)((n + T - 1) / T);
+  p->ntab = (std::max(tb + 1, p->ntiles) + tb - 1) / tb;
+  const uint32_t direct_max = c->tune_open_direct_max > 0 ? (uint32_t)c->tune_open_direct_max : TILE_DIRECT_MAX;
+  p->nsuper = p->ntiles > direct_max ? (p->ntiles + SG - 1) / SG : 0;
+  const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
+  p->z = fr_arg<F>(z);
+  Fe<F> zj = Fd::one();
+  for (uint32_t j = 0; j < SC; ++j) { memcpy(&p->ts.zs[j * F::N], zj.l, F::N * 4); zj = Fd::mul(zj, z); }
+  const Fe<F> z8 = zj;
+  zj = Fd::one();
+  for (uint32_t j = 0; j < 16; ++j) { memcpy(&p->ts.zq_lo[j * F::N], zj.l, F::N * 4); zj = Fd::mul(zj, z8); }
+  const Fe<F> z128 = zj;
+  zj = Fd::one();
+  for (uint32_t j = 0; j < 16; ++j) { memcpy(&p->ts.zq_hi[j * F::N], zj.l, F::N * 4); zj = Fd::mul(zj, z128); }
+  Fe<F> g = z128;                                             // z^(8 * 16) -> z^(8 * tb) = z^T
+  for (uint32_t q = 16; q < tb; q <<= 1) g = Fd::mul(g, g);
+  for (uint32_t s = 0; s < TILE_GW; ++s) { memcpy(&p->ts.gw[s * F::N], g.l, F::N * 4); g = Fd::mul(g, g); }
+  p->z_inv = Fd::inv(z);
+  g = p->z_inv;
+  for (uint32_t q = 0; q < SC_LOG; ++q) g = Fd::mul(g, g);    // z^-8
+  for (uint32_t s = 0; s < 9; ++s) { memcpy(&p->ts.ginv[s * F::N], g.l, F::N * 4); g = Fd::mul(g, g); }
+  const size_t words = ((size_t)p->ntiles * tb + (p->ntiles + 1) + (p->nsuper + 1) + (tb + 1) + p->ntiles) * F::N;
+  int rc = ensure_buf(c, c->scan_tmp, words * 4);
+  if (rc) return rc;
+  p->G = static_cast<uint32_t*>(c->scan_tmp.p);
+  p->H = p->G + (size_t)p->ntiles * tb * F::N;
+  p->A = p->H + (size_t)(p->ntiles + 1) * F::N;
+  p->zinv = p->A + (size_t)(p->nsuper + 1) * F::N;
+  p->W = p->zinv + (size_t)(tb + 1) * F::N;
+  return KZG_OK;
+}
+
+// plain combination: out[t] = sum_i xi^(i+1) p_i[t]  (any k <= 64)
+template <class F>
+int launch_lincomb(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
+                   const uint32_t* xi_words, uint32_t* d_out, size_t n) {
+  using Fd = Field<F>;
   LincombArgs la{};
   la.polys = d_polys; la.stride = stride; la.k = (uint32_t)k;
   const Fe<F> xi = Fd::to_mont(Fd::from_words(xi_words));
@@ -310,92 +491,71 @@ int open_combine_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k
     memcpy(&la.xipow[i * F::N], xp.l, F::N * 4);
     la.lens[i] = (uint32_t)lens[i];
   }
-  if (z_words && n > SC) {
-    if ((rc = ensure_buf(c, c->poly_tmp[2], (scan_level_entries(n) + 1) * F::N * 4))) return rc;
-    ZPowArgs zp{};
-    const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
-    Fe<F> zj = Fd::one();
-    for (uint32_t j = 0; j < SC; ++j) {
-      const Fe<F> zr = Fd::reduce(zj);
-      memcpy(&zp.l[j * F::N], zr.l, F::N * 4);
-      zj = Fd::mul(zj, z);
-    }
-    hipLaunchKernelGGL(lincomb_eval_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, zp,
-                       d_comb, (uint32_t)n, static_cast<uint32_t*>(c->poly_tmp[2].p));
-  } else {
-    hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_comb,
-                       (uint32_t)n);
-  }
+  hipLaunchKernelGGL(lincomb_kernel<F>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, la, d_out,
+                     (uint32_t)n);
   KZG_HIP(c, hipGetLastError());
   return KZG_OK;
 }
 
-// Suffix-Horner scan of comb[0 .. n) (n >= 1) at z: eval <- S_0, quot[j-1] <- S_j.  `cap` fixes the layout.
-// eval_out: host memory that receives S_0 (the call then synchronises the stream), or nullptr: nothing is copied and
-// nothing waits -- the pipelined open fetches the 32 bytes at comb + cap*8 itself (msm.hip, commit_device).
-template <class F>
-int open_scan_t(Ctx* c, size_t n, size_t cap, const uint32_t* z_words, uint64_t* eval_out, bool sync = true,
-                bool h1_ready = false) {
+// pass 1: combination + chunk / tile aggregates + tables.  More than TILE_MAXK polynomials are combined first and
+// pass 1 then runs over the combination itself (weight one).
+template <class F, uint32_t TB>
+int launch_tile_combine(Ctx* c, const TilePlan<F>& p, const uint32_t* d_polys, const size_t* lens, size_t k,
+                        size_t stride, const uint32_t* xi_words, uint32_t* d_comb, size_t n) {
   using Fd = Field<F>;
-  std::vector<uint32_t> m{(uint32_t)n};
-  while (m.back() > SC) m.push_back((m.back() + SC - 1) / SC);
-  const size_t nl = m.size();
-  std::vector<FrArg> zp(nl);                              // z^(SC^l), Montgomery form, passed by value
-  {
-    Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
-    for (size_t l = 0; l < nl; ++l) {
-      memcpy(zp[l].l, t.l, F::N * 4);
-      for (uint32_t q = 0; q < SC_LOG; ++q) t = Fd::mul(t, t);        // ^(2^SC_LOG) = ^SC
+  TileLincomb la{};
+  if (k > TILE_MAXK) {
+    int rc = launch_lincomb<F>(c, d_polys, lens, k, stride, xi_words, d_comb, n);
+    if (rc) return rc;
+    la.polys = d_comb; la.stride = n; la.k = 1; la.lens[0] = (uint32_t)n;
+    const Fe<F> one = Fd::one();
+    memcpy(&la.xipow[0], one.l, F::N * 4);
+  } else {
+    la.polys = d_polys; la.stride = stride; la.k = (uint32_t)k;
+    const Fe<F> xi = Fd::to_mont(Fd::from_words(xi_words));
+    Fe<F> xp = Fd::one();
+    for (size_t i = 0; i < k; ++i) {
+      xp = Fd::mul(xp, xi);                                 // xi^(i+1): kzg.py:148-150
+      memcpy(&la.xipow[i * F::N], xp.l, F::N * 4);
+      la.lens[i] = (uint32_t)lens[i];
     }
   }
-  size_t hl_total = 0, sl_total = 0;
-  for (size_t l = 1; l < nl; ++l) { hl_total += m[l]; sl_total += m[l] + 1; }
-  int rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[2], (hl_total + 1) * F::N * 4))) return rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[3], (sl_total + 2) * F::N * 4))) return rc;
-  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
-  uint32_t* d_eval = d_comb + cap * 8;
-  uint32_t* d_quot = d_eval + 8;
-  uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
-  uint32_t* d_S = static_cast<uint32_t*>(c->poly_tmp[3].p);
-
-  ProfScope ps(c, "open_poly");
-  auto zpow = [&](size_t l) { return zp[l]; };
-  std::vector<uint32_t*> hptr(nl, nullptr), sptr(nl, nullptr);
-  {
-    uint32_t* hp = d_h; uint32_t* sp = d_S;
-    for (size_t l = 1; l < nl; ++l) { hptr[l] = hp; hp += (size_t)m[l] * F::N; sptr[l] = sp; sp += (size_t)(m[l] + 1) * F::N; }
-  }
-  (void)d_quot;
-  if (nl == 1) {
-    // n <= SC: a single chunk; its carry is zero.  Use a one-entry zero suffix array.
-    KZG_HIP(c, hipMemsetAsync(d_S, 0, 2 * F::N * 4, c->stream));
-    hipLaunchKernelGGL(chunk_fill_final_kernel<F>, dim3(1), dim3(FILL_TB), 0, c->stream, d_comb, m[0], zpow(0), d_S,
-                       d_eval);
-  } else {
-    if (!h1_ready)     // (the fused combination of open_quotient_t has left h_1 already)
-      hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, d_comb, m[0],
-                         zpow(0), hptr[1]);
-    for (size_t l = 1; l + 1 < nl; ++l)
-      hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
-                         m[l], zpow(l), hptr[l + 1]);
-    hipLaunchKernelGGL(top_suffix_kernel<F>, dim3(1), dim3(64), 0, c->stream, hptr[nl - 1], m[nl - 1], zpow(nl - 1),
-                       sptr[nl - 1]);
-    for (size_t l = nl - 2; l >= 1; --l)
-      hipLaunchKernelGGL((chunk_fill_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hptr[l],
-                         m[l], zpow(l), sptr[l + 1], sptr[l], (uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(chunk_fill_final_kernel<F>, dim3((m[0] + FILL_EPB - 1) / FILL_EPB), dim3(FILL_TB), 0, c->stream,
-                       d_comb, m[0], zpow(0), sptr[1], d_eval);
-  }
+  hipLaunchKernelGGL((tile_combine_kernel<F, TB>), dim3(p.ntiles + p.ntab), dim3(TB), 0, c->stream, la, p.ts, d_comb,
+                     (uint32_t)n, p.ntiles, p.G, p.H, p.zinv, p.W);
   KZG_HIP(c, hipGetLastError());
-  if (eval_out) {
-    KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
-    KZG_HIP(c, hipStreamSynchronize(c->stream));
+  if (p.nsuper) {
+    hipLaunchKernelGGL(tile_group_kernel<F>, dim3(p.nsuper), dim3(64), 0, c->stream, p.H, p.W, p.ntiles, p.A);
+    KZG_HIP(c, hipGetLastError());
   }
-  (void)sync;
   return KZG_OK;
 }
 
+template <class F, uint32_t TB>
+int launch_tile_fill(Ctx* c, const TilePlan<F>& p, const uint32_t* d_comb, size_t n, const FrArg* hv, uint32_t* d_S) {
+  FrArg none{};
+  hipLaunchKernelGGL((tile_fill_kernel<F, TB>), dim3(p.ntiles), dim3(TB), 0, c->stream, d_comb, (uint32_t)n, p.ntiles,
+                     p.G, p.H, p.nsuper ? p.A : (const uint32_t*)nullptr, p.nsuper, hv ? *hv : none, hv ? 1u : 0u, p.z,
+                     p.zinv, p.W, d_S);
+  KZG_HIP(c, hipGetLastError());
+  return KZG_OK;
+}
+
+template <class F>
+int check_open_args(Ctx* c, const size_t* lens, size_t k, size_t stride, size_t* n_out) {
+  if (k > MAXK) return set_err(c, KZG_ERR_ARG, "kzg_open: more than 64 polynomials");
+  size_t n = 0;
+  for (size_t i = 0; i < k; ++i) {
+    if (lens[i] > stride) return set_err(c, KZG_ERR_ARG, "kzg_open: lens[i] > stride");
+    n = std::max(n, lens[i]);
+  }
+  if (n >= (1ull << 31) - 1) return set_err(c, KZG_ERR_ARG, "kzg_open: polynomial too long");
+  *n_out = n;
+  return KZG_OK;
+}
+
+// witness of kzg.py:153-154: eval <- S_0, quotient coefficient j-1 <- S_j.  ONE "open_poly" span per opening.
+// eval_out: host memory that receives S_0 when `sync` (the call then waits for the stream); otherwise nothing is
+// copied and nothing waits -- the pipelined open fetches the 32 bytes below the quotient itself (msm.hip).
 template <class F>
 int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                     const uint32_t* z_words, const uint32_t* xi_words, uint32_t** d_quot_out, size_t* quot_len,
@@ -404,44 +564,117 @@ int open_quotient_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t 
   *quot_len = 0;
   *d_quot_out = nullptr;
   size_t n = 0;
-  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n, z_words);
+  int rc = check_open_args<F>(c, lens, k, stride, &n);
   if (rc) return rc;
   if (n == 0) return KZG_OK;     // all polynomials zero: witness 0, evaluation 0
-  if ((rc = open_scan_t<F>(c, n, n + 1, z_words, sync ? eval_out : nullptr, sync, /*h1_ready=*/n > SC))) return rc;
-  *d_quot_out = static_cast<uint32_t*>(c->poly_tmp[0].p) + (n + 1) * 8 + 8;
+  if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * (n + 1) + 1) * 32))) return rc;
+  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
+  uint32_t* d_eval = d_comb + (n + 1) * 8;
+  {
+    ProfScope ps(c, "open_poly");
+    if (words_are_zero(z_words)) {         // S_j = c_j: the combination IS the vector of suffix values
+      if ((rc = launch_lincomb<F>(c, d_polys, lens, k, stride, xi_words, d_eval, n))) return rc;
+    } else {
+      TilePlan<F> p;
+      const uint32_t tb = open_tile_threads(c);
+      if ((rc = tile_plan<F>(c, n, z_words, tb, &p))) return rc;
+      rc = tb == 128 ? launch_tile_combine<F, 128>(c, p, d_polys, lens, k, stride, xi_words, d_comb, n)
+                     : launch_tile_combine<F, 256>(c, p, d_polys, lens, k, stride, xi_words, d_comb, n);
+      if (rc) return rc;
+      rc = tb == 128 ? launch_tile_fill<F, 128>(c, p, d_comb, n, nullptr, d_eval)
+                     : launch_tile_fill<F, 256>(c, p, d_comb, n, nullptr, d_eval);
+      if (rc) return rc;
+    }
+  }
+  if (sync && eval_out) {
+    KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+    KZG_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  *d_quot_out = d_eval + 8;
   *quot_len = n - 1;
   return KZG_OK;
 }
 
-// Sharded open, step 1: combine this rank's coefficient slices and evaluate the slice polynomial
-// (local indexing) at z.
+// Sharded open, step 1: combine this rank's coefficient slices and evaluate the slice polynomial (local indexing)
+// at z.  The combination, its chunk values and tile aggregates stay on the device for step 2.
 template <class F>
 int open_shard_begin_t(Ctx* c, const uint32_t* d_polys, const size_t* lens, size_t k, size_t stride,
                        const uint32_t* z_words, const uint32_t* xi_words, uint64_t* chunk_eval_out) {
   memset(chunk_eval_out, 0, 32);
   size_t n = 0;
-  int rc = open_combine_t<F>(c, d_polys, lens, k, stride, xi_words, &n);
+  int rc = check_open_args<F>(c, lens, k, stride, &n);
   if (rc) return rc;
   c->open_shard_n = n;
+  c->open_shard_tb = 0;
   if (n == 0) return KZG_OK;
-  return open_scan_t<F>(c, n, n + 1, z_words, chunk_eval_out);
+  if ((rc = ensure_buf(c, c->poly_tmp[0], (2 * (n + 1) + 1) * 32))) return rc;
+  uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
+  uint32_t* d_eval = d_comb + (n + 1) * 8;
+  {
+    ProfScope ps(c, "open_shard_poly");
+    if (words_are_zero(z_words)) {         // slice(0) = its constant coefficient
+      if ((rc = launch_lincomb<F>(c, d_polys, lens, k, stride, xi_words, d_comb, n))) return rc;
+      KZG_HIP(c, hipMemcpyAsync(chunk_eval_out, d_comb, 32, hipMemcpyDeviceToHost, c->stream));
+    } else {
+      TilePlan<F> p;
+      const uint32_t tb = open_tile_threads(c);
+      if ((rc = tile_plan<F>(c, n, z_words, tb, &p))) return rc;
+      rc = tb == 128 ? launch_tile_combine<F, 128>(c, p, d_polys, lens, k, stride, xi_words, d_comb, n)
+                     : launch_tile_combine<F, 256>(c, p, d_polys, lens, k, stride, xi_words, d_comb, n);
+      if (rc) return rc;
+      if (tb == 128)
+        hipLaunchKernelGGL((tile_eval_kernel<F, 128>), dim3(1), dim3(128), 0, c->stream, p.ntiles, p.H,
+                           p.nsuper ? p.A : (const uint32_t*)nullptr, p.nsuper, p.W, d_eval);
+      else
+        hipLaunchKernelGGL((tile_eval_kernel<F, 256>), dim3(1), dim3(256), 0, c->stream, p.ntiles, p.H,
+                           p.nsuper ? p.A : (const uint32_t*)nullptr, p.nsuper, p.W, d_eval);
+      KZG_HIP(c, hipGetLastError());
+      c->open_shard_tb = tb;
+      KZG_HIP(c, hipMemcpyAsync(chunk_eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
+  return KZG_OK;
 }
 
-// step 2: with the carry S_hi of the ranks above appended as an extra top coefficient the scan
-// yields S_lo .. S_(hi-1) exactly (linearity).  Returns the vector to commit.
+// step 2: the carry S_hi of the ranks above enters the fill as the aggregate of a virtual tile above the slice
+// (exact: S_j of the slice depends on what lies above only through S_hi).  Returns the vector to commit.
 template <class F>
 int open_shard_finish_t(Ctx* c, const uint32_t* z_words, const uint32_t* carry_words, int first_rank,
                         uint32_t** d_vec_out, size_t* vec_len, uint64_t* eval_out) {
+  using Fd = Field<F>;
   memset(eval_out, 0, 32);
   *d_vec_out = nullptr;
   *vec_len = 0;
   const size_t n = c->open_shard_n;
   if (n == 0) return KZG_OK;
   uint32_t* d_comb = static_cast<uint32_t*>(c->poly_tmp[0].p);
-  KZG_HIP(c, hipMemcpyAsync(d_comb + n * 8, carry_words, 32, hipMemcpyHostToDevice, c->stream));
-  int rc = open_scan_t<F>(c, n + 1, n + 1, z_words, eval_out);
-  if (rc) return rc;
   uint32_t* d_eval = d_comb + (n + 1) * 8;
+  int rc;
+  {
+    ProfScope ps(c, "open_shard_poly");
+    if (words_are_zero(z_words)) {         // S_j = c_j for every j below the slice's end
+      KZG_HIP(c, hipMemcpyAsync(d_eval, d_comb, n * 32, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      const uint32_t tb = c->open_shard_tb;
+      if (tb != 128 && tb != 256) return set_err(c, KZG_ERR_ARG, "kzg_open_shard_finish without kzg_open_shard_begin");
+      TilePlan<F> p;
+      if ((rc = tile_plan<F>(c, n, z_words, tb, &p))) return rc;       // same z, same tiles: same buffers and tables
+      // virtual tile `ntiles`: its aggregate is S at index ntiles * T, i.e. carry * z^-(ntiles * T - n)
+      const size_t gap = (size_t)p.ntiles * tb * SC - n;
+      Fe<F> hv = Fd::from_words(carry_words), zi = p.z_inv;
+      for (size_t e = gap; e; e >>= 1) {
+        if (e & 1) hv = Fd::mul(hv, zi);
+        zi = Fd::mul(zi, zi);
+      }
+      const FrArg hva = fr_arg<F>(hv);
+      rc = tb == 128 ? launch_tile_fill<F, 128>(c, p, d_comb, n, &hva, d_eval)
+                     : launch_tile_fill<F, 256>(c, p, d_comb, n, &hva, d_eval);
+      if (rc) return rc;
+    }
+  }
+  KZG_HIP(c, hipMemcpyAsync(eval_out, d_eval, 32, hipMemcpyDeviceToHost, c->stream));
+  KZG_HIP(c, hipStreamSynchronize(c->stream));
   if (first_rank) {            // S_0 is the evaluation; the quotient slice is S_1 .. S_(n-1)
     *d_vec_out = d_eval + 8;
     *vec_len = n - 1;

@@ -1,7 +1,8 @@
 """The C-ABI boundary defends itself:
   * the pipelined entry points (kzg_commit_device_async / kzg_open_device_async) keep raw host pointers until
     kzg_commit_flush: the Python context holds the arrays (and the key) for exactly that long;
-  * kzg_ctx_set_stream adopts only handles the HIP runtime knows as streams;
+  * kzg_ctx_set_stream refuses what cannot be a stream handle (HIP cannot validate one: the caller guarantees a live
+    stream, the library asks nothing of the runtime);
   * a failed opening leaves no stale evaluation pointer in its pipeline slot."""
 import gc
 import os
@@ -97,9 +98,9 @@ def test_failed_open_leaves_no_stale_evaluation_pointer(native):
 def test_set_stream_refuses_what_cannot_be_a_stream():
     """gpurun_out/r02_crash.log: a non-handle passed to kzg_ctx_set_stream used to reach hipEventRecord.  HIP cannot
     validate a handle (hipStreamQuery dereferences it: a readable buffer that is no stream crashed the child of this
-    test's first version, profiles/r03_stream_query_crash.log), so the library refuses what cannot be a runtime object
-    -- small integers other than the two documented aliases, misaligned values -- and takes real streams and the
-    aliases.  Run in a child process: a regression here is a host crash, which must not take the session down."""
+    test's first version, profiles/r03_stream_query_crash.log; round 4 dropped the query altogether), so the library
+    refuses what cannot be a runtime object -- small integers other than the two documented aliases, misaligned
+    values -- and takes real streams and the aliases; liveness of anything else is the caller's guarantee.  Run in a child process: a regression here is a host crash, which must not take the session down."""
     code = r'''
 import sys
 sys.path.insert(0, %r)

@@ -624,35 +624,112 @@ def test_commit_2_20_with_extreme_coefficients(native, kzgs):
 
 @pytest.mark.parametrize("curve", CURVES)
 def test_open_at_the_tile_boundaries_of_its_kernels(native, kzgs, curve):
-    """The combination groups six products per reduction (Field::dot), its workgroup of 256 coefficients also leaves the
-    bottom level of the evaluation, and the last fill works on tiles of 1024: k = 1 .. 13 polynomials (one to three
-    groups, every remainder) of lengths around those tile sizes, coefficients r-1 / 0 / random, against the trapdoor
-    identity open == ((P(tau) - P(z)) / (tau - z)) G1 and P(z) against the oracle's Horner (kzg.py:148-154)."""
+    """The combination groups six products per reduction (Field::dot) and takes at most sixteen polynomials per
+    launch; the scan works on chunks of 8 coefficients and tiles of 1024 or 2048 (128 / 256 threads), every tile
+    summing the aggregates of the tiles above it: k = 1 .. 18 polynomials (one to three groups, every remainder, and
+    the pre-combined form beyond sixteen) of lengths around those sizes with both tile widths, coefficients r-1 / 0 /
+    random, against the trapdoor identity open == ((P(tau) - P(z)) / (tau - z)) G1 and P(z) against the oracle's
+    Horner (kzg.py:148-154)."""
     cv = O.curve(curve)
     r = cv.r
     kzg = kzgs[curve]
     tau = 0xfeedface12345 % r
-    ck, _ = kzg.setup(2100, tau=tau)
+    ck, _ = kzg.setup(4200, tau=tau)
     ctx = native.get_context(curve)
     rng = random.Random(1234)
     L = ctx.fp_limbs
-    for n, k in ((255, 1), (256, 2), (257, 3), (1023, 4), (1024, 5), (1025, 6), (2049, 7), (9, 8), (8, 9), (513, 11), (2047, 13)):
-        lens = [max(1, n - 3 * i) for i in range(k)]
-        polys = []
-        for i, m in enumerate(lens):
-            kind = (i + n) % 3
-            polys.append([r - 1] * m if kind == 0 else [rng.randrange(r) for _ in range(m)] if kind == 1
-                         else [(r - 1) if j % 2 else 0 for j in range(m)])
-        arr = np.zeros((k, n, 4), dtype=np.uint64)
-        for i, p in enumerate(polys):
-            arr[i, :len(p)] = native.ints_to_limbs(p)
-        z, xi = (r - 1, r - 1) if n % 2 else (rng.randrange(r), rng.randrange(r))
-        xy, inf, ev = ctx.open(ck.srs, arr, lens, n, native.int_to_words(z), native.int_to_words(xi))
-        comb = O.combine(polys, xi, r)
-        assert native.limbs_to_ints(ev.reshape(1, 4))[0] == O.poly_eval(comb, z, r), (n, k)
-        want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
-        got = None if inf[0] else tuple(native.limbs_to_ints(xy.reshape(2, L)))
-        assert got == want, (n, k)
+    cases = ((1, 1), (2, 2), (7, 3), (255, 1), (256, 2), (257, 3), (1023, 4), (1024, 5), (1025, 6), (2049, 7), (9, 8),
+             (8, 9), (513, 11), (2047, 13), (2048, 16), (4097, 17), (3071, 18), (4100, 2))
+    try:
+        for tb in (128, 256):
+            ctx.set_tuning("open_tile_threads", tb)
+            for n, k in cases:
+                lens = [max(1, n - 3 * i) for i in range(k)]
+                polys = []
+                for i, m in enumerate(lens):
+                    kind = (i + n) % 3
+                    polys.append([r - 1] * m if kind == 0 else [rng.randrange(r) for _ in range(m)] if kind == 1
+                                 else [(r - 1) if j % 2 else 0 for j in range(m)])
+                arr = np.zeros((k, n, 4), dtype=np.uint64)
+                for i, p in enumerate(polys):
+                    arr[i, :len(p)] = native.ints_to_limbs(p)
+                z, xi = (r - 1, r - 1) if n % 2 else (rng.randrange(r), rng.randrange(r))
+                xy, inf, ev = ctx.open(ck.srs, arr, lens, n, native.int_to_words(z), native.int_to_words(xi))
+                comb = O.combine(polys, xi, r)
+                assert native.limbs_to_ints(ev.reshape(1, 4))[0] == O.poly_eval(comb, z, r), (tb, n, k)
+                want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
+                got = None if inf[0] else tuple(native.limbs_to_ints(xy.reshape(2, L)))
+                assert got == want, (tb, n, k)
+    finally:
+        ctx.set_tuning("open_tile_threads", 0)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_open_with_grouped_tile_aggregates(native, kzgs, curve):
+    """Beyond 1024 tiles (polynomials of more than 2^21 coefficients) the aggregates of 64 tiles are folded into one
+    before the tiles sum what lies above them.  The same path forced at a size the oracle walks in seconds
+    (`open_direct_tiles` = 1): 150,001 and 65,536 coefficients = 147 / 64 tiles of 1024 in 3 / 1 groups and 74 / 32
+    tiles of 2048; the quotient's commitment against the trapdoor identity, P(z) against the oracle, and both equal
+    to what the ungrouped path returns."""
+    cv = O.curve(curve)
+    r = cv.r
+    kzg = kzgs[curve]
+    tau = 0x5eed5eed77 % r
+    ck, _ = kzg.setup(150001, tau=tau)
+    ctx = native.get_context(curve)
+    rng = random.Random(99)
+    L = ctx.fp_limbs
+    try:
+        for n, k in ((150001, 2), (65536, 3)):
+            lens = [n - 5 * i for i in range(k)]
+            polys = [[rng.randrange(r) for _ in range(m)] for m in lens]
+            arr = np.zeros((k, n, 4), dtype=np.uint64)
+            for i, p in enumerate(polys):
+                arr[i, :len(p)] = native.ints_to_limbs(p)
+            z, xi = rng.randrange(r), rng.randrange(r)
+            comb = O.combine(polys, xi, r)
+            want_ev = O.poly_eval(comb, z, r)
+            want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
+            for tb in (128, 256):
+                for direct in (1, 0):
+                    ctx.set_tuning("open_tile_threads", tb)
+                    ctx.set_tuning("open_direct_tiles", direct)
+                    xy, inf, ev = ctx.open(ck.srs, arr, lens, n, native.int_to_words(z), native.int_to_words(xi))
+                    assert native.limbs_to_ints(ev.reshape(1, 4))[0] == want_ev, (n, tb, direct)
+                    got = None if inf[0] else tuple(native.limbs_to_ints(xy.reshape(2, L)))
+                    assert got == want, (n, tb, direct)
+    finally:
+        ctx.set_tuning("open_tile_threads", 0)
+        ctx.set_tuning("open_direct_tiles", 0)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_one_open_poly_span_per_opening(native, kzgs, curve):
+    """kzg_prof_read("open_poly") counts ONE span per opening (round 3 opened two scopes and halved the stage time the
+    bench reported), on the synchronous and on the pipelined entry point."""
+    import torch
+    kzg = kzgs[curve]
+    r = O.curve(curve).r
+    ck, _ = kzg.setup(3000, tau=12345)
+    ctx = native.get_context(curve)
+    rng = random.Random(5)
+    n, k = 2500, 3
+    arr = native.ints_to_limbs([rng.randrange(r) for _ in range(n * k)]).reshape(k, n, 4)
+    d = torch.from_numpy(arr.view(np.int64)).cuda()
+    z, xi = native.int_to_words(rng.randrange(r)), native.int_to_words(rng.randrange(r))
+    ctx.prof_enable(True)
+    try:
+        ctx.prof_reset()
+        for _ in range(3):
+            ctx.open(ck.srs, d.data_ptr(), [n] * k, n, z, xi, device=True)
+        outs = [(np.zeros(2 * ctx.fp_limbs, np.uint64), np.zeros(1, np.uint8), np.zeros(4, np.uint64)) for _ in range(4)]
+        for o in outs:
+            ctx.open_device_async(ck.srs, d.data_ptr(), [n] * k, n, z, xi, *o)
+        ctx.commit_flush()
+        ms, cnt = ctx.prof_read("open_poly")
+        assert cnt == 7 and ms > 0
+    finally:
+        ctx.prof_enable(False)
 
 
 @pytest.mark.parametrize("key_log", [15, 18])

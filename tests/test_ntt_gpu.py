@@ -399,12 +399,27 @@ def test_transform_beside_a_commit_in_flight(native, curve):
             torch.cuda.synchronize()
             ctx.ntt_device(alone.data_ptr(), log_n, ww, inverse, 1)                  # nothing in flight
             ctx.synchronize()
+            assert ctx.prof_read("ntt_tile_log")[0] == 11
             xy, inf = np.zeros((4, 2 * L), dtype=np.uint64), np.zeros(4, dtype=np.uint8)
             ctx.commit_device_async(srs, d_sc.data_ptr(), [n_key] * 4, n_key, xy, inf)   # four MSMs queued
             ctx.ntt_device(busy.data_ptr(), log_n, ww, inverse, 1)                   # beside them
+            took = ctx.prof_read("ntt_tile_log")[0]          # 10 unless the four MSMs had already left the queue
             ctx.commit_flush()
             ctx.synchronize()
             assert np.array_equal(alone.cpu().numpy().view(np.uint64), want), (log_n, inverse, "alone")
             assert np.array_equal(busy.cpu().numpy().view(np.uint64), want), (log_n, inverse, "beside a commit")
-            assert int(inf.sum()) == 0
+            assert int(inf.sum()) == 0 and took in (10, 11)
+            # the choice above rides on an event query; both tiles (and the 4096-element one of the experiments)
+            # deterministically through the override, so that neither path can regress unseen
+            for tile_log in (10, 11, 12):
+                ctx.set_tuning("ntt_tile_log", tile_log)
+                try:
+                    forced = torch.from_numpy(raw.view(np.int64)).to("cuda:0")
+                    torch.cuda.synchronize()
+                    ctx.ntt_device(forced.data_ptr(), log_n, ww, inverse, 1)
+                    ctx.synchronize()
+                    assert ctx.prof_read("ntt_tile_log")[0] == tile_log
+                finally:
+                    ctx.set_tuning("ntt_tile_log", 0)
+                assert np.array_equal(forced.cpu().numpy().view(np.uint64), want), (log_n, inverse, tile_log)
     srs.close()

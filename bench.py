@@ -386,7 +386,9 @@ def section_open(env, srs, n):
                       "ms_per_open": elapsed_async / iters * 1e3,
                       "entry": "kzg_open_device_async + kzg_commit_flush"},
         "verified": {"proof_trapdoor": bool(ok), "combined_eval": bool(ok_ev), "pipelined_equals_synchronous": bool(ok_async)},
-        "roofline": {"kernel": "open_poly: lincomb + chunk_eval + scan + chunk_fill (csrc/poly.hip)", "bound": "hbm",
+        "poly_stage_spans": int(poly_cnt),                 # == iters: ONE open_poly span per opening
+        "roofline": {"kernel": "open_poly: tile_combine_kernel + tile_fill_kernel (csrc/poly.hip), one span per opening",
+                     "bound": "hbm",
                      "achieved": alg_bytes / avg_s / 1e9 if avg_s > 0 else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_bytes / avg_s / 1e9 / HBM_PEAK_GBPS if avg_s > 0 else None, "traffic": traffic,
                      "algorithmic_bytes_per_open": alg_bytes},

@@ -147,7 +147,7 @@ __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size
 //     elements t, t + TB, ..); e = comb * z^(pos mod 8); the 8 products of a chunk are added across 8 adjacent lanes by
 //     DPP (lazily: 8 limbs of 29 bits stay below 2^32) -> h_q = sum_(r<8) c_(8q+r) z^r; g_q = h_q z^(8q); the tile's
 //     aggregate H_b = sum_q g_q = sum_(i<T) c_(bT+i) z^i.  Written: comb (32 B per coefficient), g (36 B per chunk),
-//     H (36 B per tile).  Extra workgroups at the end of the grid build the two tables pass 2 reads: zinv[q] = z^(-8q)
+//     H (36 B per tile).  Extra workgroups at the head of the grid build the two tables pass 2 reads: zinv[q] = z^(-8q)
 //     (q <= TB) and W[k] = z^(T(k+1)), from a few generator powers the host passes in the kernel arguments.
 //   pass 2 (tile_fill_kernel): every tile sums the aggregates ABOVE it itself, Q_b = z^T S_((b+1)T) = sum_(k>=0) H_(b+1+k) W[k]
 //     -- one product per tile pair, 1.3 * 10^5 products at 2^20, spread over all workgroups: there is no serial chain
@@ -165,6 +165,10 @@ constexpr uint32_t SG_LOG = 6, SG = 1u << SG_LOG;      // tiles per group of the
 constexpr uint32_t TILE_MAXK = 16;                     // polynomials per tile_combine launch (more: combined first)
 constexpr uint32_t TILE_GW = 22;                       // generator powers z^(T 2^s) for the W table: 2^22 tiles
 constexpr uint32_t TILE_DIRECT_MAX = 1024;             // up to this many tiles every tile sums all aggregates above it
+#ifndef KZG_TILE_ITER
+#define KZG_TILE_ITER 4
+#endif
+constexpr uint32_t TILE_ITER = KZG_TILE_ITER;          // coefficients per thread of the combination (tile_combine_kernel)
 
 struct TileLincomb {
   const uint32_t* polys;
@@ -224,30 +228,34 @@ __device__ __forceinline__ Fe<F> pow_from_generators(const uint32_t* g, uint32_t
   return p;
 }
 
-template <class F, uint32_t TB>
-__global__ __launch_bounds__(TB) void tile_combine_kernel(TileLincomb a, TileScanArgs ts, uint32_t* comb, uint32_t n,
-                                                          uint32_t ntiles, uint32_t* G, uint32_t* H, uint32_t* zinv,
-                                                          uint32_t* W) {
+// TB chunks (T = 8 TB coefficients) per tile, TK = T / ITER threads per workgroup: the kernel waits for memory, so the
+// coefficients of a tile are spread over MORE threads than the fill uses (2 waves per SIMD at one thread per chunk:
+// 77 us for the 2^20 x 6 combination; profiles/r04a_open_kernel_stats.csv), each taking ITER strided elements.
+template <class F, uint32_t TB, uint32_t ITER>
+__global__ __launch_bounds__(TB * SC / ITER) void tile_combine_kernel(TileLincomb a, TileScanArgs ts, uint32_t* comb,
+                                                                      uint32_t n, uint32_t ntiles, uint32_t* G,
+                                                                      uint32_t* H, uint32_t* zinv, uint32_t* W) {
   using Fd = Field<F>;
-  static_assert(F::N == FRN && SC == 8 && TB % 64 == 0 && TB <= 256, "tile layout");
-  constexpr uint32_t T = TB * SC;
+  constexpr uint32_t T = TB * SC, TK = T / ITER;
+  static_assert(F::N == FRN && SC == 8 && TB % 64 == 0 && TB <= 256 && TK % 64 == 0 && TK >= TB && TK <= 1024, "tile layout");
   __shared__ uint32_t hs[TB * FRN];                         // chunk sums (lazy limbs)
   __shared__ uint32_t zsh[SC * FRN];
-  __shared__ uint32_t red[(TB / 8 + TB / 64) * FRN];
+  __shared__ uint32_t red[(TK / 8 + TK / 64) * FRN];
   const uint32_t tid = threadIdx.x;
-  if (blockIdx.x >= ntiles) {                               // table workgroups: nothing of pass 1 reads these
-    const uint32_t t = (blockIdx.x - ntiles) * TB + tid;
+  const uint32_t ntab = gridDim.x - ntiles;
+  if (blockIdx.x < ntab) {       // table workgroups (nothing of pass 1 reads these): FIRST in the grid, so that their
+    const uint32_t t = blockIdx.x * TK + tid;               // chains of <= 20 products start at once and end early
     if (t <= TB) store_limbs<F>(zinv + (size_t)t * F::N, pow_from_generators<F>(ts.ginv, t));
     if (t < ntiles) store_limbs<F>(W + (size_t)t * F::N, pow_from_generators<F>(ts.gw, t + 1));
     return;
   }
-  const uint32_t b = blockIdx.x, base = b * T;
+  const uint32_t b = blockIdx.x - ntab, base = b * T;
   if (tid < SC * FRN) zsh[tid] = ts.zs[tid];
   __syncthreads();
   const Fe<F> zr = load_limbs<F>(zsh + (tid & (SC - 1)) * F::N);
 #pragma unroll 1
-  for (uint32_t it = 0; it < SC; ++it) {
-    const uint32_t i = it * TB + tid, t = base + i;
+  for (uint32_t it = 0; it < ITER; ++it) {
+    const uint32_t i = it * TK + tid, t = base + i;
     Fe<F> acc = Fd::zero();
     if (t < n) {
       for (uint32_t i0 = 0; i0 < a.k; i0 += DOT_G) {
@@ -272,11 +280,14 @@ __global__ __launch_bounds__(TB) void tile_combine_kernel(TileLincomb a, TileSca
     if ((tid & 7) == 0) store_limbs<F>(hs + (i >> 3) * F::N, s);
   }
   __syncthreads();
-  const Fe<F> hq = Fd::reduce_wide(Fd::carry(load_limbs<F>(hs + tid * F::N)));
-  const Fe<F> zq = Fd::mul(load_limbs<F>(ts.zq_lo + (tid & 15) * F::N), load_limbs<F>(ts.zq_hi + (tid >> 4) * F::N));
-  const Fe<F> g = Fd::mul(hq, zq);
-  store_limbs<F>(G + ((size_t)b * TB + tid) * F::N, g);
-  const Fe<F> hb = block_sum<F, TB>(g, red);
+  Fe<F> g = Fd::zero();
+  if (tid < TB) {                                                             // whole waves: TB is a multiple of 64
+    const Fe<F> hq = Fd::reduce_wide(Fd::carry(load_limbs<F>(hs + tid * F::N)));
+    const Fe<F> zq = Fd::mul(load_limbs<F>(ts.zq_lo + (tid & 15) * F::N), load_limbs<F>(ts.zq_hi + (tid >> 4) * F::N));
+    g = Fd::mul(hq, zq);
+    store_limbs<F>(G + ((size_t)b * TB + tid) * F::N, g);
+  }
+  const Fe<F> hb = block_sum<F, TK>(g, red);
   if (tid == 0) store_limbs<F>(H + (size_t)b * F::N, hb);
 }
 
@@ -443,10 +454,10 @@ static uint32_t open_tile_threads(Ctx* c) {
 template <class F>
 int tile_plan(Ctx* c, size_t n, const uint32_t* z_words, uint32_t tb, TilePlan<F>* p) {
   using Fd = Field<F>;
-  const uint32_t T = tb * SC;
+  const uint32_t T = tb * SC, tk = T / TILE_ITER;
   p->tb = tb;
   p->ntiles = (uint32_t)((n + T - 1) / T);
-  p->ntab = (std::max(tb + 1, p->ntiles) + tb - 1) / tb;
+  p->ntab = (std::max(tb + 1, p->ntiles) + tk - 1) / tk;
   const uint32_t direct_max = c->tune_open_direct_max > 0 ? (uint32_t)c->tune_open_direct_max : TILE_DIRECT_MAX;
   p->nsuper = p->ntiles > direct_max ? (p->ntiles + SG - 1) / SG : 0;
   const Fe<F> z = Fd::to_mont(Fd::from_words(z_words));
@@ -520,8 +531,8 @@ int launch_tile_combine(Ctx* c, const TilePlan<F>& p, const uint32_t* d_polys, c
       la.lens[i] = (uint32_t)lens[i];
     }
   }
-  hipLaunchKernelGGL((tile_combine_kernel<F, TB>), dim3(p.ntiles + p.ntab), dim3(TB), 0, c->stream, la, p.ts, d_comb,
-                     (uint32_t)n, p.ntiles, p.G, p.H, p.zinv, p.W);
+  hipLaunchKernelGGL((tile_combine_kernel<F, TB, TILE_ITER>), dim3(p.ntiles + p.ntab), dim3(TB * SC / TILE_ITER), 0,
+                     c->stream, la, p.ts, d_comb, (uint32_t)n, p.ntiles, p.G, p.H, p.zinv, p.W);
   KZG_HIP(c, hipGetLastError());
   if (p.nsuper) {
     hipLaunchKernelGGL(tile_group_kernel<F>, dim3(p.nsuper), dim3(64), 0, c->stream, p.H, p.W, p.ntiles, p.A);

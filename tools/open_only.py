@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Opening-only driver for profiling: `iters` KZG.open calls of k polynomials of 2^log_n coefficients
 (kzg.py:122-159; plonk/prover.py:184 opens k = 6), device-resident inputs, synchronous entry point -- so every
-lincomb_kernel / chunk_eval_kernel / chunk_fill_kernel launch a profiler sees belongs to an opening.
+tile_combine_kernel / tile_fill_kernel launch a profiler sees belongs to an opening.
 
     python tools/open_only.py [log_n=20] [k=6] [iters=10]"""
 import os

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the opening's polynomial stage (csrc/poly.hip: lincomb_kernel, chunk_eval_kernel,
-# chunk_fill_kernel, top_suffix_kernel; kzg.py:148-154) under rocprofv3 -- kernel-trace stats, then FETCH_SIZE,
+# Runs on the GPU box (via gpurun): the opening's polynomial stage (csrc/poly.hip: tile_combine_kernel,
+# tile_fill_kernel; kzg.py:148-154) under rocprofv3 -- kernel-trace stats, then FETCH_SIZE,
 # WRITE_SIZE and SQ_INSTS_VALU in separate --pmc passes (kernel-trace only, the program directly after `--`).
 #   tools/profile_open.sh <tag>   -> gpurun_out/prof_open_<tag>/ ; then: python tools/summarize_open.py <tag>
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_open_$TAG
 rm -rf $OUT; mkdir -p $OUT

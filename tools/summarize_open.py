@@ -2,7 +2,7 @@
 """Condenses tools/profile_open.sh's output (gpurun_out/prof_open_<tag>) into profiles/<tag>_open_kernel_stats.csv and
 profiles/<tag>_open_pmc.csv and adds the entry "open_poly" to profiles/counters.json (what bench.py reports as
 open.roofline.traffic): HBM bytes and VALU wave-instructions PER OPENING, i.e. summed over the launches one opening
-issues (1 lincomb + the levels of chunk_eval / chunk_fill + top_suffix).  Units and the gfx950 FETCH_SIZE correction
+issues (round 4: tile_combine + tile_fill; rounds 1-3: 1 lincomb + the levels of chunk_eval / chunk_fill + top_suffix).  Units and the gfx950 FETCH_SIZE correction
 as in tools/summarize_profile.py (MI355X_MICROARCH.md, HBM section)."""
 import collections
 import csv
@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_open_" + tag)
 dst = os.path.join(ROOT, "profiles")
 POLY = ("lincomb_kernel", "lincomb_eval_kernel", "chunk_eval_kernel", "chunk_fill_kernel", "chunk_fill_final_kernel",
-        "top_suffix_kernel")
+        "top_suffix_kernel", "tile_combine_kernel", "tile_group_kernel", "tile_fill_kernel", "tile_eval_kernel")
+FIRST = ("lincomb_kernel", "lincomb_eval_kernel", "tile_combine_kernel")      # one launch of these per opening
 
 
 def short(name):
@@ -31,7 +32,7 @@ def one(pattern):
 
 
 rows = list(csv.DictReader(open(one("trace/**/*kernel_stats.csv"))))
-n_open = sum(int(r["Calls"]) for r in rows if short(r["Name"]) in ("lincomb_kernel", "lincomb_eval_kernel"))   # one per opening
+n_open = sum(int(r["Calls"]) for r in rows if short(r["Name"]) in FIRST)
 with open(os.path.join(dst, f"{tag}_open_kernel_stats.csv"), "w") as f:
     f.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns,calls_per_opening,ns_per_opening\n")
     for r in rows:

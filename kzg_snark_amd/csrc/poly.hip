@@ -14,6 +14,7 @@
 #include "internal.h"
 #include "msm.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -168,6 +169,13 @@ constexpr uint32_t TILE_DIRECT_MAX = 1024;             // up to this many tiles 
 #ifndef KZG_TILE_ITER
 #define KZG_TILE_ITER 4
 #endif
+// Issue priority of the two tile kernels.  Beside an accumulate kernel they hold a wave slot and ~110 VGPRs per SIMD
+// that the reduce stage's 168-VGPR waves then cannot get: at priority 0 the combination of opening p + 1 sat there for
+// 1.4 ms and rc1 / rc2 / prep_binsort stretched 4-17x (gpurun_out/trace_open_a); raised, it is gone after 0.48 ms:
+// 448 vs 430 pipelined opens/s, same box, alternating (profiles/r04_open_async_ab.txt).
+#ifndef KZG_TILE_PRIO
+#define KZG_TILE_PRIO 3
+#endif
 constexpr uint32_t TILE_ITER = KZG_TILE_ITER;          // coefficients per thread of the combination (tile_combine_kernel)
 
 struct TileLincomb {
@@ -242,6 +250,9 @@ __global__ __launch_bounds__(TB * SC / ITER) void tile_combine_kernel(TileLincom
   __shared__ uint32_t zsh[SC * FRN];
   __shared__ uint32_t red[(TK / 8 + TK / 64) * FRN];
   const uint32_t tid = threadIdx.x;
+#if KZG_TILE_PRIO
+  __builtin_amdgcn_s_setprio(KZG_TILE_PRIO);
+#endif
   const uint32_t ntab = gridDim.x - ntiles;
   if (blockIdx.x < ntab) {       // table workgroups (nothing of pass 1 reads these): FIRST in the grid, so that their
     const uint32_t t = blockIdx.x * TK + tid;               // chains of <= 20 products start at once and end early
@@ -351,6 +362,9 @@ __global__ __launch_bounds__(TB) void tile_fill_kernel(const uint32_t* comb, uin
   __shared__ uint32_t red[(TB / 8 + TB / 64) * FRN];
   __shared__ uint32_t wsum[NWAVE * FRN];
   __shared__ uint32_t qsh[FRN];
+#if KZG_TILE_PRIO
+  __builtin_amdgcn_s_setprio(KZG_TILE_PRIO);
+#endif
   const uint32_t tid = threadIdx.x, b = blockIdx.x, e0 = b * T;
   const uint4* gin = reinterpret_cast<const uint4*>(comb);
   for (uint32_t i = tid; i < T * 2; i += TB) {
@@ -448,6 +462,8 @@ static bool words_are_zero(const uint32_t* w) {
 // a workgroup onto every CU (the transform makes the same choice, ntt.hip).  c->tune_open_tb fixes it (tests).
 static uint32_t open_tile_threads(Ctx* c) {
   if (c->tune_open_tb == 128 || c->tune_open_tb == 256) return (uint32_t)c->tune_open_tb;
+  static const int fixed = [] { const char* e = getenv("KZG_OPEN_TB"); return e ? atoi(e) : 0; }();      // experiments
+  if (fixed == 128 || fixed == 256) return (uint32_t)fixed;
   return msm_accumulate_in_flight(c) ? 128u : 256u;
 }
 

@@ -3,7 +3,10 @@
 (kzg.py:122-159; plonk/prover.py:184 opens k = 6), device-resident inputs, synchronous entry point -- so every
 tile_combine_kernel / tile_fill_kernel launch a profiler sees belongs to an opening.
 
-    python tools/open_only.py [log_n=20] [k=6] [iters=10]"""
+    python tools/open_only.py [log_n=20] [k=6] [iters=10] [async]
+
+`async`: the same openings through kzg_open_device_async + kzg_commit_flush (witness MSMs pipelined, the polynomial
+stage of opening p + 1 beside the accumulate kernel of opening p); prints opens/s."""
 import os
 import sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -24,6 +27,25 @@ d = x.to("cuda:0")
 torch.cuda.synchronize()
 lens = [n - i for i in range(k)]
 z, xi = _native.int_to_words(0x1111111111111111111111111111), _native.int_to_words(0x2222222222222222222222)
+if len(sys.argv) > 4 and sys.argv[4] == "async":
+    import time
+    import numpy as np
+    L = ctx.fp_limbs
+    outs = [(np.zeros(2 * L, np.uint64), np.zeros(1, np.uint8), np.zeros(4, np.uint64)) for _ in range(iters)]
+    for o in outs[:4]:
+        ctx.open_device_async(srs, d.data_ptr(), lens, n, z, xi, *o)
+    ctx.commit_flush()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for o in outs:
+        ctx.open_device_async(srs, d.data_ptr(), lens, n, z, xi, *o)
+    ctx.commit_flush()
+    dt = time.perf_counter() - t0
+    ms, cnt = ctx.prof_read("open_poly")
+    print(f"pipelined: {iters / dt:.1f} opens/s ({dt / iters * 1e3:.3f} ms per opening); open_poly span beside the MSMs "
+          f"{ms / max(cnt, 1) * 1e3:.1f} us over {cnt} openings (k = {k}, 2^{log_n})")
+    sys.exit(0)
 ctx.prof_enable(True)
 for i in range(iters):
     if i == 2:

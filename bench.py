@@ -24,6 +24,8 @@ The same JSON line also carries
                                          verified against the trapdoor identities (n_gpus = 1: the whole job);
   * distributed_ntt                      (N >= 2) the four-step 2^24 transform over RCCL all-to-all, verified
                                          against the single-GPU transform;
+  * range_mode_2p20 / distributed_ntt_2p20   (N >= 2) the same two at the metric's own degree 2^20: strong scaling of
+                                         ONE commit + open and ONE transform over the ranks;
   * plonk_round                          (N = 1) BASELINE config 5: index -> prove -> verify of a synthetic 2^20-gate
                                          circuit, prover resident on the GPU; ms per prover round, verifier accepts;
   * cpu_baseline / cpu_baseline_optimised   rank 0 at N = 1: the oracle's C restatement of the reference
@@ -398,15 +400,17 @@ def section_open(env, srs, n):
     }, bool(ok and ok_ev and ok_async)
 
 
-def section_range(env):
-    """BASELINE config 4: k polynomials of 2^log_n coefficients and the commitment key split by contiguous
+def section_range(env, log_n=None, steps=None):
+    """BASELINE config 4 (log_n = None: --range-log-n, 24), and the same step at the metric's own degree (log_n = 20:
+    strong scaling of ONE commit + open over the ranks): k polynomials of 2^log_n coefficients and the commitment key split by contiguous
     coefficient range over the ranks.  Step = commit of polynomial 0 + open of all k:
     every rank runs a whole local MSM per operation; what crosses ranks is one field element (open) and one
     point per rank per operation, all-gathered as fixed-size records and added on the host by every rank."""
     from kzg_snark_amd.sharding import DistributedCommitter, all_gather_bytes, range_of
     args, ctx, nat, kzg, r = env.args, env.ctx, env.native, env.kzg, env.r
     world, rank = env.world, env.rank
-    log_n, k = args.range_log_n, args.open_k
+    log_n, k = (args.range_log_n if log_n is None else log_n), args.open_k
+    n_steps = args.range_steps if steps is None else steps
     n = 1 << log_n
     lo, hi = range_of(rank, world, n)
     m = hi - lo
@@ -451,7 +455,7 @@ def section_range(env):
         step()
     env.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.range_steps):
+    for _ in range(n_steps):
         commitment, (proof, ev) = step()
     env.barrier()
     elapsed = env.max_over_ranks(time.perf_counter() - t0)
@@ -468,8 +472,8 @@ def section_range(env):
     del cshard, oshard, sl
     out = {
         "metric": f"KZG commit + open of k = {k} per second, degree-2^{log_n} polynomials sharded by coefficient range",
-        "value": args.range_steps / elapsed, "unit": "commit+open/s", "n_gpus": world, "steps": args.range_steps,
-        "ms_per_step": elapsed / args.range_steps * 1e3, "scaling": "strong",
+        "value": n_steps / elapsed, "unit": "commit+open/s", "n_gpus": world, "steps": n_steps,
+        "ms_per_step": elapsed / n_steps * 1e3, "scaling": "strong",
         "log_n": log_n, "k": k, "coefficients_per_rank": m,
         "exchange": "per step: one 32-byte field element per rank, then one record of two 97-byte G1 points "
                     "(+ P(z)) per rank, all-gathered as uint8 tensors and added on the host; the two local MSMs "
@@ -538,14 +542,14 @@ def section_plonk(env):
     return out, ok and same
 
 
-def section_dist_ntt(env):
-    """The four-step transform of 2^log_n elements sharded over the ranks (sharding.DistributedNTT): forward
+def section_dist_ntt(env, log_n=None):
+    """The four-step transform of 2^log_n elements (None: --range-log-n, 24; 20: the metric's own degree) sharded over the ranks (sharding.DistributedNTT): forward
     in natural order (three all-to-alls), inverse into the transposed layout (two).  Every rank also runs
     the whole transform alone and compares its shard."""
     from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps, transposed_index
     args, ctx, nat, torch = env.args, env.ctx, env.native, env.torch
     world, rank = env.world, env.rank
-    log_n = args.range_log_n
+    log_n = args.range_log_n if log_n is None else log_n
     k1 = (log_n + 1) // 2
     N1, N2 = 1 << k1, 1 << (log_n - k1)
     if world & (world - 1) or N1 % world or N2 % world or log_n <= 12:
@@ -771,6 +775,15 @@ def main(argv=None):
         run_section("range_mode", section_range, env)
     if args.mode == "all" and env.collective and not args.no_dist_ntt:
         run_section("distributed_ntt", section_dist_ntt, env)
+    # strong scaling at the metric's own degree (BASELINE.json: "commits/sec + NTT elements/sec at degree 2^20, 1/2/4/8
+    # MI355X"): ONE degree-2^log_n commit + open split by coefficient range, and ONE 2^log_n transform over the
+    # all-to-alls -- the headline `value` above is batch mode (independent polynomials per rank, weak scaling)
+    if args.mode == "all" and env.collective and args.range_log_n != log_n:
+        tag = "2p%d" % log_n
+        if not args.no_range:
+            run_section("range_mode_" + tag, section_range, env, log_n, max(args.range_steps, 20))
+        if not args.no_dist_ntt:
+            run_section("distributed_ntt_" + tag, section_dist_ntt, env, log_n)
     if args.mode == "all" and not args.no_plonk:
         run_section("plonk_round", section_plonk, env)
 

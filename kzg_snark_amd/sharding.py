@@ -63,20 +63,50 @@ def unpack_point(rec):
 FORCE_COLLECTIVES = False
 
 
+_gather_bufs = {}       # (group id, device, payload length, world) -> (send, recv) uint8 tensors, reused across calls
+
+
 def all_gather_bytes(payload, group=None, always=False):
     """Every rank contributes `payload` (same length everywhere); returns the list of all ranks'
-    payloads in rank order.  One all_gather of a uint8 tensor: on the current CUDA device under
-    RCCL ("nccl"), on the host under gloo.  `always`: issue the collective even in a one-rank group
-    (tests: the RCCL call path on a single GPU)."""
+    payloads in rank order.  One all_gather_into_tensor of uint8 records.  Under RCCL ("nccl") the
+    records stay on the device between the two copies this needs: ONE host-to-device copy of the
+    payload into a buffer kept per (group, length), the collective, ONE device-to-host copy of the
+    whole gathered block (round 3 built a tensor per call and fetched every rank's record with its
+    own .cpu(): a device synchronisation per rank and exchange).  Under gloo the tensors are host
+    memory.  `always`: issue the collective even in a one-rank group (tests: the RCCL call path on
+    a single GPU)."""
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not (always or FORCE_COLLECTIVES)):
         return [bytes(payload)]
     world = dist.get_world_size(group)
+    n = len(payload)
+    if n == 0:
+        return [b""] * world
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+    key = (id(group) if group is not None else 0, str(dev), n, world)
+    bufs = _gather_bufs.get(key)
+    if bufs is None:
+        if len(_gather_bufs) > 64:
+            _gather_bufs.clear()
+        send = torch.empty(n, dtype=torch.uint8, device=dev)
+        recv = torch.empty(n * world, dtype=torch.uint8, device=dev)
+        stage = torch.empty(n, dtype=torch.uint8).pin_memory() if on_gpu else None
+        back = torch.empty(n * world, dtype=torch.uint8).pin_memory() if on_gpu else None
+        bufs = _gather_bufs[key] = (send, recv, stage, back)
+    send, recv, stage, back = bufs
+    src = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    if on_gpu:
+        stage.copy_(src)
+        send.copy_(stage, non_blocking=True)             # ordered on the current stream, like the collective
+        dist.all_gather_into_tensor(recv, send, group=group)
+        back.copy_(recv, non_blocking=True)
+        torch.cuda.current_stream().synchronize()        # the one wait of the exchange
+        blob = back.numpy().tobytes()
+    else:
+        send.copy_(src)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        blob = recv.numpy().tobytes()
+    return [blob[g * n:(g + 1) * n] for g in range(world)]
 
 
 class DistributedCommitter:

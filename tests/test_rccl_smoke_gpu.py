@@ -40,11 +40,11 @@ def test_one_rank_rccl_group_takes_the_calls_the_multi_gpu_paths_make():
         f = torch.tensor([1], device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         assert int(f.item()) == 1
-        # sharding.all_gather_bytes: fixed-size uint8 records
+        # sharding.all_gather_bytes: fixed-size uint8 records, gathered into ONE device tensor
         rec = torch.frombuffer(bytearray(range(97)), dtype=torch.uint8).to(dev)
-        outs = [torch.empty_like(rec)]
-        dist.all_gather(outs, rec)
-        assert bytes(outs[0].cpu().numpy().tobytes()) == bytes(range(97))
+        block = torch.empty(97, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(block, rec)
+        assert bytes(block.cpu().numpy().tobytes()) == bytes(range(97))
         # sharding.DistributedNTT.exchange: blocks of 32-byte field elements as int64[.., 4]
         send = torch.arange(4 * 1024, dtype=torch.int64, device=dev).view(1024, 4).contiguous()
         recv = torch.empty_like(send)
@@ -60,6 +60,16 @@ def test_one_rank_rccl_group_takes_the_calls_the_multi_gpu_paths_make():
         from kzg_snark_amd.sharding import DistributedNTT, GpuNttOps, all_gather_bytes, pack_point, unpack_point
         pt = (12345, 67890, 1)
         assert [unpack_point(b) for b in all_gather_bytes(pack_point(pt), always=True)] == [pt]
+        # the gather keeps one device buffer per record length and reuses it: repeated exchanges of two lengths,
+        # interleaved, return what was put in (and allocate nothing new)
+        from kzg_snark_amd import sharding as _sh
+        before = len(_sh._gather_bufs)
+        for i in range(6):
+            rec32, rec97 = bytes([i] * 32), bytes([(i * 7 + j) % 251 for j in range(97)])
+            assert all_gather_bytes(rec32, always=True) == [rec32]
+            assert all_gather_bytes(rec97, always=True) == [rec97]
+        assert len(_sh._gather_bufs) == before + 1            # 97-byte records had their buffer already
+        assert all_gather_bytes(b"", always=True) == [b""]
         ctx = _native.get_context("bls12_381")
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):

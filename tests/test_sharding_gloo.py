@@ -12,6 +12,11 @@ import torch.multiprocessing as mp
 from oracle import py_oracle as O
 
 
+import datetime
+
+_PG_TIMEOUT = datetime.timedelta(seconds=240)        # a rank whose peer died gives up instead of waiting half an hour
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -20,10 +25,40 @@ def _free_port():
     return p
 
 
+def _run_ranks(target, world, timeout, extra=()):
+    """Spawn `world` ranks of `target(rank, world, port, queue, *extra)` and collect one result each.  Whatever goes
+    wrong -- a rank that raised leaves its peers blocked in a gloo collective, a queue that stays empty -- every
+    child is terminated (then killed) before the error travels on: no process is left holding the GPU or the port,
+    and pytest does not hang joining non-daemon children."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q, *extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = []
+        for _ in range(world):
+            res.append(q.get(timeout=timeout))
+            if res[-1][1] != "ok":                      # its peers may never return from their collective
+                break
+        for p in procs:
+            p.join(timeout=60 if len(res) == world and all(v == "ok" for _, v in res) else 1)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    return res
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     try:
         from kzg_snark_amd import curve as C
         from kzg_snark_amd.sharding import DistributedCommitter, range_of
@@ -156,7 +191,7 @@ def _ntt_worker(rank, world, port, q):
     import torch
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     try:
         from kzg_snark_amd.sharding import DistributedNTT
         cv = O.BLS12_381
@@ -188,30 +223,12 @@ def test_two_rank_distributed_ntt():
     """The all-to-all choreography of the multi-GPU four-step NTT (natural order in; natural order
     out with three exchanges or the transposed layout with two; arbitrary w, inverse) with the
     oracle as the local transform."""
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_ntt_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_ranks(_ntt_worker, 2, 180)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
 def test_two_rank_exchange():
-    world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_ranks(_worker, 2, 120)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
@@ -249,7 +266,7 @@ def _plonk_worker(rank, world, port, q, device):
     import sys
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         if here not in sys.path:
@@ -311,15 +328,7 @@ def _plonk_worker(rank, world, port, q, device):
 
 
 def _run_plonk_ranks(world, device, timeout):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_plonk_worker, args=(r, world, port, q, device)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=timeout) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_ranks(_plonk_worker, world, timeout, (device,))
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 

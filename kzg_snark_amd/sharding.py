@@ -218,9 +218,12 @@ class ProofSharding:
     with the same proof dict.  What crosses ranks is one all-gather of fixed-size records per round (pack_point),
     plus one broadcast per dealt transform."""
 
-    def __init__(self, group=None, deal_transforms=False):
+    def __init__(self, group=None, deal_transforms=False, shard_vectors=False):
+        """shard_vectors: split the proof's VECTOR work over the ranks as well (plonk_sharded.ShardedProver through
+        plonk_sharded.make_prover; power-of-two world sizes) instead of replicating it beside dealt MSMs."""
         self.group = group
         self.deal_transforms = bool(deal_transforms)
+        self.shard_vectors = bool(shard_vectors)
         self.exchanges = 0          # collectives issued (tests / bench bookkeeping)
 
     @property
@@ -410,3 +413,182 @@ class GpuNttOps:
         n_rows = recv.shape[1]
         self.ctx.ntt_rows_exchange_device(recv.data_ptr(), out.data_ptr(), self.log_n, self.w, self.inverse, n_rows,
                                           world, blocked)
+
+
+# =====================================================================================================
+# Pieces of the VECTOR-sharded prover (kzg_snark_amd/plonk_sharded.py): tensor collectives and the three
+# distributed transforms it needs.  Tensors are int64 [m, 4] views of canonical Fr elements; under gloo a
+# CUDA tensor makes the round trip through the host (rehearsal on one GPU), under RCCL it stays on the device.
+# =====================================================================================================
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def _collective_on(group=None):
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
+def all_gather_tensor(t, group=None):
+    """[G * m, ...]: every rank's `t` (same shape everywhere) concatenated in rank order."""
+    t = t.contiguous()
+    if not _collective_on(group):
+        return t.clone()
+    world = dist.get_world_size(group)
+    host_trip = t.is_cuda and dist.get_backend(group) != "nccl"
+    src = t.cpu() if host_trip else t
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(t.device) if host_trip else out
+
+
+def all_to_all_rows(send, send_rows, recv_rows, group=None):
+    """Variable all-to-all along dim 0: the first send_rows[0] rows of `send` go to rank 0, the next send_rows[1] to
+    rank 1, ..; returns what the ranks sent us, in rank order (recv_rows[h] rows from rank h)."""
+    send = send.contiguous()
+    if not _collective_on(group):
+        assert list(send_rows) == list(recv_rows)
+        return send.clone()
+    host_trip = send.is_cuda and dist.get_backend(group) != "nccl"
+    src = send.cpu() if host_trip else send
+    out = torch.empty((sum(recv_rows),) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_to_all_single(out, src, output_split_sizes=list(recv_rows), input_split_sizes=list(send_rows), group=group)
+    return out.to(send.device) if host_trip else out
+
+
+class ShardedTransforms:
+    """The transforms of a prover whose vectors are split over G ranks (G a power of two):
+
+      natural(x, log_n, w, inverse)        n-point NTT / INTT, contiguous range per rank in AND out
+                                           (DistributedNTT, layout "natural": three all-to-alls);
+      padded_to_T(x, log_n, log_big, w)    the first n = 2^log_n entries of a zero-padded 2^log_big vector (contiguous
+                                           range of n/G per rank) -> its transform in the TRANSPOSED layout of the
+                                           2^log_big four-step (two all-to-alls; only the n/N2' non-zero rows of the
+                                           N1' x N2' view travel in the first one);
+      T_to_natural(x, log_big, w, inverse) transposed layout in -> contiguous range out: one all-to-all + a local
+                                           transpose bring the data into range order, then `natural`.
+
+    The transposed layout of a 2^L transform over G ranks: rank g holds [R1][N2] (R1 = N1 / G), element (t, b) being
+    index b * N1 + g * R1 + t (transposed_index).  Element-wise work does not care about the order as long as every
+    vector of one domain uses the same one.
+
+    Below `min_log` (the device passes need more than one 4096-element tile: log_n > 12) or when G does not divide
+    the matrix sides, a transform gathers the whole vector, runs it locally and keeps its own part -- the sizes where
+    that happens are the sizes where a vector is a few kilobytes.
+
+    make_ops(log_n, w, inverse) -> the local halves for DistributedNTT (GpuNttOps on the device);
+    full_ntt(t, w, inverse)     -> whole in-place transform of a local tensor."""
+
+    def __init__(self, make_ops, full_ntt, group=None, min_log=13):
+        self.make_ops, self.full_ntt, self.group, self.min_log = make_ops, full_ntt, group, min_log
+        self.exchanges = 0
+
+    @property
+    def world(self):
+        return _world(self.group)
+
+    @property
+    def rank(self):
+        return _rank(self.group)
+
+    def _distributed(self, log_n):
+        G = self.world
+        k1 = (log_n + 1) // 2
+        return log_n >= self.min_log and (1 << (log_n - k1)) % G == 0 and G & (G - 1) == 0
+
+    def _dntt(self, log_n, w, inverse):
+        d = DistributedNTT(self.make_ops(log_n, w, inverse), group=self.group)
+        return d
+
+    def t_index(self, log_n, device):
+        """global index of every element of this rank's transposed-layout shard of a 2^log_n vector"""
+        G, g = self.world, self.rank
+        k1 = (log_n + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_n - k1)
+        if N1 % G:
+            raise ValueError("world size must divide 2^ceil(log_n / 2)")
+        i = torch.arange((N1 // G) * N2, device=device)
+        return (i % N2) * N1 + g * (N1 // G) + i // N2
+
+    # ---- natural -> natural
+    def natural(self, x, log_n, w, inverse):
+        n, G, g = 1 << log_n, self.world, self.rank
+        assert x.shape[0] * G == n
+        if self._distributed(log_n):
+            self.exchanges += 3
+            return self._dntt(log_n, w, inverse).transform(x, log_n, layout="natural")
+        self.exchanges += 1
+        full = all_gather_tensor(x, self.group)
+        self.full_ntt(full, w, inverse)
+        m = n // G
+        return full[g * m:(g + 1) * m].clone()
+
+    # ---- first n entries of a zero-padded 2^log_big vector -> transposed layout
+    def padded_to_T(self, x, log_n, log_big, w):
+        n, G, g = 1 << log_n, self.world, self.rank
+        m = n // G
+        assert x.shape[0] == m and log_big >= log_n
+        k1 = (log_big + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_big - k1)
+        if self._distributed(log_big) and m % N2 == 0 and N1 % G == 0:
+            R1, W, Rh = N1 // G, N2 // G, m // N2                      # my rows of the N1 x N2 view: g * Rh ..
+            send = x.view(Rh, G, W, 4).permute(1, 0, 2, 3).contiguous()
+            d = self._dntt(log_big, w, False)
+            got = d.exchange(send)                                     # [G][Rh][W]: rows h * Rh + r, my W columns
+            M = torch.zeros((N1, W, 4), dtype=x.dtype, device=x.device)
+            M[:G * Rh] = got.view(G * Rh, W, 4)
+            d.ops.columns(M, g * W)
+            recv = d.exchange(M.view(G, R1, W, 4))
+            out = torch.empty_like(recv)
+            d.ops.rows_exchange(recv, out, G, False)
+            self.exchanges += 2
+            return out.view(R1 * N2, 4)
+        self.exchanges += 1
+        full = torch.zeros((1 << log_big, 4), dtype=x.dtype, device=x.device)
+        full[:n] = all_gather_tensor(x, self.group)
+        self.full_ntt(full, w, False)
+        return full.index_select(0, self.t_index(log_big, x.device))
+
+    # ---- transposed layout -> natural range (then an ordinary distributed transform)
+    def T_to_natural(self, x, log_big, w, inverse):
+        G, g = self.world, self.rank
+        k1 = (log_big + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_big - k1)
+        R1, W = N1 // G, N2 // G
+        assert x.shape[0] == R1 * N2
+        if self._distributed(log_big):
+            d = self._dntt(log_big, w, inverse)
+            send = x.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()       # block h: my rows, rank h's outputs
+            got = d.exchange(send)                                            # [G][R1][W]: rows s * R1 + t, my W columns
+            nat = got.view(N1, W, 4).permute(1, 0, 2).contiguous().view(W * N1, 4)
+            self.exchanges += 4
+            return d.transform(nat, log_big, layout="natural")
+        self.exchanges += 1
+        parts = all_gather_tensor(x, self.group).view(G, R1 * N2, 4)
+        full = torch.empty((1 << log_big, 4), dtype=x.dtype, device=x.device)
+        i = torch.arange(R1 * N2, device=x.device)
+        for h in range(G):
+            full[(i % N2) * N1 + h * R1 + i // N2] = parts[h]
+        self.full_ntt(full, w, inverse)
+        m = (1 << log_big) // G
+        return full[g * m:(g + 1) * m].clone()
+
+    # ---- neighbours in the transposed layout: y[i] = x[(i + shift) mod 2^log_big], 0 < shift <= R1
+    def T_shift(self, x, log_big, shift):
+        G, g = self.world, self.rank
+        k1 = (log_big + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_big - k1)
+        R1 = N1 // G
+        if not 0 < shift <= R1:
+            raise ValueError("shift must be within one rank's rows")
+        rows = x.view(R1, N2, 4)
+        self.exchanges += 1
+        heads = all_gather_tensor(rows[:shift].contiguous(), self.group).view(G, shift, N2, 4)
+        nxt = heads[(g + 1) % G]
+        if g == G - 1:          # residues wrap: index b * N1 + (rho + shift - N1) + N1 = (b + 1) * N1 + ..
+            nxt = torch.roll(nxt, shifts=-1, dims=1)
+        return torch.cat([rows[shift:], nxt], dim=0).contiguous().view(R1 * N2, 4)

@@ -130,60 +130,13 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-class _OracleNttOps:
-    """Local halves of the distributed NTT on Python ints (the oracle's fft_ff)."""
-
-    def __init__(self, log_n, w, r, inverse):
-        self.k1 = (log_n + 1) // 2
-        self.k2 = log_n - self.k1
-        self.r = r
-        self.n = 1 << log_n
-        self.w = pow(w, -1, r) if inverse else w
-        self.scale = pow(self.n, -1, r) if inverse else 1
-
-    @staticmethod
-    def _ints(t):
-        import numpy as np
-        a = np.ascontiguousarray(t.numpy().view(np.uint64))
-        raw = a.tobytes()
-        return [int.from_bytes(raw[i:i + 32], "little") for i in range(0, len(raw), 32)]
-
-    @staticmethod
-    def _put(t, vals):
-        import numpy as np
-        import torch
-        buf = b"".join(int(v).to_bytes(32, "little") for v in vals)
-        t.copy_(torch.from_numpy(np.frombuffer(buf, dtype="<i8").reshape(t.shape).copy()))
-
-    def columns(self, M, col_base):
-        N1, W = M.shape[0], M.shape[1]
-        vals = self._ints(M)
-        root = pow(self.w, 1 << self.k2, self.r)
-        out = [0] * (N1 * W)
-        for c in range(W):
-            col = O.fft_ff([vals[t * W + c] for t in range(N1)], root, self.r)
-            for t in range(N1):
-                out[t * W + c] = col[t] * pow(self.w, t * (col_base + c), self.r) % self.r
-        self._put(M, out)
-
-    def rows_exchange(self, recv, out, world, blocked):
-        """recv: [G][R1][W] blocks as the columns -> rows all-to-all delivers them; out: the same
-        blocked shape over the output index (blocked) or plain [R1][N2] rows."""
-        G, R1, W = recv.shape[0], recv.shape[1], recv.shape[2]
-        assert G == world
-        N2 = G * W
-        vals = self._ints(recv)
-        root = pow(self.w, 1 << self.k1, self.r)
-        res = [0] * (R1 * N2)
-        for t in range(R1):
-            row = [vals[(v // W) * R1 * W + t * W + (v % W)] for v in range(N2)]
-            tr = [v * self.scale % self.r for v in O.fft_ff(row, root, self.r)]
-            for b in range(N2):
-                if blocked:
-                    res[(b // W) * R1 * W + t * W + (b % W)] = tr[b]
-                else:
-                    res[t * N2 + b] = tr[b]
-        self._put(out, res)
+def _oracle_backends():
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import oracle_backends
+    return oracle_backends
 
 
 def _ntt_worker(rank, world, port, q):
@@ -204,12 +157,13 @@ def _ntt_worker(rank, world, port, q):
             lo, hi = rank * n // world, (rank + 1) * n // world
             buf = b"".join(v.to_bytes(32, "little") for v in x[lo:hi])
             xl = torch.from_numpy(np.frombuffer(buf, dtype="<i8").reshape(hi - lo, 4).copy())
-            d = DistributedNTT(_OracleNttOps(log_n, w, cv.r, inverse))
-            got = _OracleNttOps._ints(d.transform(xl.clone(), log_n))
+            OB = _oracle_backends()
+            d = DistributedNTT(OB.OracleNttOps(log_n, w, cv.r, inverse))
+            got = OB.ints_of(d.transform(xl.clone(), log_n))
             assert got == want[lo:hi], (inverse, "distributed NTT shard mismatch")
             # two all-to-alls: the result stays in the row pass's order
             from kzg_snark_amd.sharding import transposed_index
-            got_t = _OracleNttOps._ints(d.transform(xl.clone(), log_n, layout="transposed"))
+            got_t = OB.ints_of(d.transform(xl.clone(), log_n, layout="transposed"))
             assert got_t == [want[transposed_index(log_n, world, rank, i)] for i in range(hi - lo)], "transposed layout"
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
@@ -330,6 +284,94 @@ def _plonk_worker(rank, world, port, q, device):
 def _run_plonk_ranks(world, device, timeout):
     res = _run_ranks(_plonk_worker, world, timeout, (device,))
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _sharded_ipk(ipk, OB):
+    """proving key of the host indexer -> the tensors the vector-sharded prover slices (what DeviceIndexer leaves on
+    the device: coefficient vectors of the eight preprocessed polynomials, sigma* values)"""
+    n = ipk["subgroups"]["n"]
+    co = {k: OB.tensor_of(([int(c) for c in p.list()] + [0] * n)[:n]) for k, p in ipk["polynomials"].items()}
+    ss = ipk["sigma_star"]
+    sv = {f"S_sigma{b + 1}": OB.tensor_of([int(v) for v in ss[b * n:(b + 1) * n]]) for b in range(3)}
+    return {"ck": ipk["ck"], "coeffs": co, "sigma_values": sv, "subgroups": ipk["subgroups"]}
+
+
+def _proof_key(proof):
+    return (sorted((k, tuple(int(c) for c in v)) for k, v in list(proof["commitments"].items())
+                   + list(proof["kzg_proofs"].items())),
+            sorted((k, int(v)) for k, v in proof["evaluations"].items()))
+
+
+def _sharded_worker(rank, world, port, q, case):
+    """One rank of a PLONK proof whose VECTORS are split over `world` ranks (plonk_sharded.ShardedProver), the oracle
+    standing in for the engine (tests/oracle_backends.py): distributed INTTs and coset NTTs through the all-to-alls,
+    accumulator carries, quotient re-partition, range-sharded commitments and openings."""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
+    try:
+        OB = _oracle_backends()
+        import test_plonk as TP
+        from kzg_snark_amd import plonk, plonk_sharded
+        from kzg_snark_amd.field import GF, PolynomialRing
+        plonk.fft_ff_interpolation = lambda values, g, F: PolynomialRing(F, "X")(
+            O.fft_ff_interpolation([int(v) for v in values], int(g), F.p))
+        if case == "frozen":
+            gp = _golden("plonk_proof_n16.json")
+            circuit, curve, tau = TP.fixture_instance(), gp["curve"], int(gp["tau"], 16)
+            blinders = [int(v, 16) for v in gp["blinders"]]
+        else:
+            curve, tau = "bn254", 0x7a75
+            circuit = plonk.synthetic_circuit(64, GF(O.curve(curve).r), seed=3)
+            blinders = list(range(101, 112))
+        idx = plonk.Indexer(curve)
+        idx.kzg = TP.oracle_backed(curve)
+        ipk, ivk = idx.preprocess(*circuit[:6], tau=tau)
+        sp = plonk_sharded.ShardedProver(curve, OB.OracleShardBackend(curve))
+        mine = blinders if rank == 0 else [b + 1 + rank for b in blinders]       # only rank 0's count
+        proof = sp.prove(_sharded_ipk(ipk, OB), circuit[6], circuit[7], blinders=mine)
+        if case == "frozen":
+            _check_frozen_proof(proof, gp)
+        else:           # the unsharded host prover with the same blinders: the same proof, and the verifier accepts it
+            ref = plonk.Prover(curve)
+            ref.kzg = TP.oracle_backed(curve)
+            want = ref.prove(ipk, circuit[6], circuit[7], blinders=blinders)
+            assert _proof_key(proof) == _proof_key(want)
+            if rank == 0:
+                ver = plonk.Verifier(curve)
+                assert ver.verify(ivk, circuit[6], proof)
+        assert sp.tf.exchanges > 0 and sp.exchanges > 0
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "frozen"), (2, "synthetic"), (4, "synthetic")])
+def test_vector_sharded_proof_over_ranks(world, case):
+    """BASELINE config 5 with the vector work split over the ranks (plonk/prover.py:83-85, 243-264, 297-316 on range /
+    transposed shards; commitments and openings against key shards): two ranks reproduce
+    tests/golden/plonk_proof_n16.json bit for bit (n = 16 leaves a rank the minimum of 8 rows); two and four ranks
+    reproduce the unsharded host prover's proof of a 64-gate circuit, which the verifier accepts."""
+    res = _run_ranks(_sharded_worker, world, 600, (case,))
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_vector_sharding_needs_a_power_of_two_world():
+    """Three ranks cannot split the radix-2 transforms: make_prover then keeps the dealt-MSM prover (the world-size-3
+    test below), and hands out the vector-sharded one for 1, 2, 4, 8 ranks."""
+    from types import SimpleNamespace
+    from kzg_snark_amd import plonk_sharded
+    alg = SimpleNamespace(ctx=None, r=O.BN254.r)
+    for world, want in ((1, "ShardedProver"), (2, "ShardedProver"), (3, "DeviceProver"), (4, "ShardedProver"),
+                        (6, "DeviceProver"), (8, "ShardedProver")):
+        sh = SimpleNamespace(world=world, shard_vectors=True, group=None)
+        assert type(plonk_sharded.make_prover("bn254", alg, sh)).__name__ == want, world
+    sh = SimpleNamespace(world=4, shard_vectors=False, group=None)
+    assert type(plonk_sharded.make_prover("bn254", alg, sh)).__name__ == "DeviceProver"
 
 
 @pytest.mark.parametrize("world", [2, 3])

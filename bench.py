@@ -82,6 +82,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-dist-ntt", action="store_true", help="skip the distributed NTT section")
     ap.add_argument("--no-plonk", action="store_true", help="skip the config-5 PLONK round (one GPU only)")
     ap.add_argument("--plonk-log-n", type=int, default=20, help="gates of the PLONK round (config 5: 2^20)")
+    ap.add_argument("--plonk-mode", default="auto", choices=("auto", "dealt", "sharded"),
+                    help="N > 1: one proof over the ranks with its VECTOR work split as well (sharded; auto picks it "
+                         "for power-of-two world sizes) or with only the MSMs dealt over replicated vectors (dealt)")
     ap.add_argument("--range-log-n", type=int, default=24, help="degree of the range-sharded job (config 4: 24)")
     ap.add_argument("--range-steps", type=int, default=5)
     ap.add_argument("--open-k", type=int, default=6, help="polynomials per opening (plonk/prover.py:184 opens 6)")
@@ -495,7 +498,9 @@ def section_plonk(env):
     n = 1 << env.args.plonk_log_n
     # N > 1: ONE proof over the ranks -- the commitments of a round and the two openings dealt round-robin against
     # the replicated key, vector work replicated (sharding.ProofSharding); every rank ends with the same proof
-    sh = ProofSharding() if env.collective else None
+    pow2 = env.world & (env.world - 1) == 0
+    sharded = env.collective and (env.args.plonk_mode == "sharded" or (env.args.plonk_mode == "auto" and pow2 and env.world > 1))
+    sh = ProofSharding(shard_vectors=sharded) if env.collective else None
     prev = torch.cuda.current_stream(env.dev)
     t = {}
     t0 = time.perf_counter()
@@ -505,7 +510,9 @@ def section_plonk(env):
     idx = plonk_device.DeviceIndexer(env.args.curve)
     ipk, ivk = idx.preprocess(qM, qL, qR, qO, qC, perm, tau=0x706c6f6e6b if sh else None)   # one key on every rank
     t["index_s"] = time.perf_counter() - t0
-    prv = plonk_device.DeviceProver(env.args.curve, alg=idx.alg, sharding=sh)
+    from kzg_snark_amd import plonk_sharded
+    prv = plonk_sharded.make_prover(env.args.curve, idx.alg, sh)
+    sharded = type(prv).__name__ == "ShardedProver"
     env.barrier()
     t0 = time.perf_counter()
     proof = prv.prove(ipk, x, w)
@@ -528,6 +535,7 @@ def section_plonk(env):
                                             list(proof["commitments"].items()) + list(proof["kzg_proofs"].items()))
                                      ).encode()).digest()
         same = len(set(all_gather_bytes(digest))) == 1
+    exch = (prv.exchanges // 4, prv.tf.exchanges // 4) if sharded else None       # four proofs were made
     del ipk, prv, idx
     torch.cuda.set_stream(prev)
     torch.cuda.empty_cache()
@@ -535,7 +543,11 @@ def section_plonk(env):
            "value": sorted(rounds)[1] * 1e3, "unit": "ms", "higher_is_better": False, "gates": n, "n_gpus": env.world,
            "rounds_ms": [v * 1e3 for v in rounds], **t,
            "verified": {"verifier_accepts": ok, **({"same_proof_on_every_rank": same} if sh else {})}}
-    if sh is not None:
+    if sharded:
+        out["sharding"] = ("one proof over the ranks, vectors split (plonk_sharded.ShardedProver): range / transposed "
+                           "shards, distributed transforms, partial commitments and openings against key shards")
+        out["exchanges_per_proof"] = {"record_gathers": exch[0], "tensor_collectives": exch[1]}
+    elif sh is not None:
         out["sharding"] = ("one proof over the ranks: 3 + 1 + 3 commitments and the 2 openings dealt round-robin, "
                            "replicated key and vector work; %d exchanges per proof (one all-gather of 97-byte records "
                            "per round + the blinders)" % (sh.exchanges // 4))

@@ -382,6 +382,71 @@ def test_plonk_proof_dealt_over_ranks_is_the_frozen_proof(world):
     _run_plonk_ranks(world, device=False, timeout=300)
 
 
+def _sharded_gpu_worker(rank, world, port, q):
+    """The vector-sharded prover on the engine (plonk_sharded.GpuShardBackend), `world` ranks sharing the test box's
+    GPU over gloo (tensors make the round trip through the host in the exchanges)."""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=_PG_TIMEOUT)
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        if here not in sys.path:
+            sys.path.insert(0, here)
+        import test_plonk as TP
+        from kzg_snark_amd import plonk, plonk_device, plonk_sharded
+        from kzg_snark_amd.field import GF
+        from kzg_snark_amd.sharding import ProofSharding, all_gather_bytes
+        # 1. the frozen 16-gate proof (every transform below the distributed sizes: gather, transform, keep a share)
+        gp = _golden("plonk_proof_n16.json")
+        circuit = TP.fixture_instance()
+        curve, tau = gp["curve"], int(gp["tau"], 16)
+        blinders = [int(v, 16) for v in gp["blinders"]]
+        idx = plonk_device.DeviceIndexer(curve)
+        ipk, ivk = idx.preprocess(*circuit[:6], tau=tau)
+        prv = plonk_sharded.make_prover(curve, idx.alg, ProofSharding(shard_vectors=True))
+        assert type(prv).__name__ == "ShardedProver"
+        mine = blinders if rank == 0 else [b + 1 + rank for b in blinders]
+        proof = prv.prove(ipk, circuit[6], circuit[7], blinders=mine)
+        _check_frozen_proof(proof, gp)
+        assert plonk.Verifier(curve).verify(ivk, circuit[6], proof)
+        # 2. 2^12 and 2^13 gates on BLS12-381: the 4n-point (and at 2^13 the n-point) transforms go through the
+        # all-to-alls and the device's column / row passes; same blinders as the unsharded device prover -> the same
+        # proof on every rank, and the verifier accepts it
+        F = GF(O.BLS12_381.r)
+        for log_gates in (12, 13):
+            big = plonk.synthetic_circuit(1 << log_gates, F, seed=log_gates)
+            idx2 = plonk_device.DeviceIndexer("bls12_381")
+            ipk2, ivk2 = idx2.preprocess(*big[:6], tau=0x1234567)
+            bl = list(range(7, 18))
+            want = plonk_device.DeviceProver("bls12_381", alg=idx2.alg).prove(ipk2, big[6], big[7], blinders=bl)
+            sp = plonk_sharded.make_prover("bls12_381", idx2.alg, ProofSharding(shard_vectors=True))
+            got = sp.prove(ipk2, big[6], big[7], blinders=bl if rank == 0 else [1] * 11)
+            assert _proof_key(got) == _proof_key(want), log_gates
+            assert plonk.Verifier("bls12_381").verify(ivk2, big[6], got)
+            digest = hashlib.sha256(repr(_proof_key(got)).encode()).digest()
+            assert len(set(all_gather_bytes(digest))) == 1, "ranks ended with different proofs"
+            assert sp.tf.exchanges >= 29 if world > 1 else True
+            del ipk2, sp, idx2
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_vector_sharded_device_prover_on_one_gpu(world):
+    """plonk_sharded.ShardedProver on the engine: one rank (every exchange degenerate, the shard logic alone) and two
+    ranks sharing the GPU over gloo.  The frozen 16-gate proof bit for bit; 2^12- and 2^13-gate proofs identical to
+    the unsharded device prover's for the same blinders, accepted by the verifier, the same on every rank."""
+    res = _run_ranks(_sharded_gpu_worker, world, 900)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
 @pytest.mark.gpu
 def test_device_prover_dealt_over_two_ranks_on_one_gpu():
     """The same with the device prover (kzg_snark_amd/plonk_device.py), two ranks sharing the test box's GPU over

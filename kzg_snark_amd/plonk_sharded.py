@@ -308,23 +308,26 @@ class ShardedProver:
         shards, the six coefficients above X^(3n) and whether anything non-zero lies beyond them."""
         be, G, g = self.be, self.world, self.rank
         m = n // G
-        blocks = [[] for _ in range(G)]                       # per destination: (beta, tensor)
+        # equal-sized slots (cap blocks per destination; unused ones travel as they are): an all-to-all with uniform
+        # splits is the collective every backend implements the same way
+        cap = max(1, 4 // G)
+        send = torch.zeros((G, cap, m, 4), dtype=t_nat.dtype, device=t_nat.device)
+        fill = [0] * G
         for j in range(4):
             beta = 4 * g + j
             if beta < 3 * G:
-                blocks[beta % G].append(t_nat[j * m:(j + 1) * m])
-        send_rows = [m * len(b) for b in blocks]
-        recv_rows = [m * sum(1 for beta in range(4 * s, 4 * s + 4) if beta < 3 * G and beta % G == g) for s in range(G)]
-        flat = [t for b in blocks for t in b]
-        send = torch.cat(flat).contiguous() if flat else t_nat[:0]
+                d = beta % G
+                send[d, fill[d]] = t_nat[j * m:(j + 1) * m]
+                fill[d] += 1
         self.tf.exchanges += 1
-        got = all_to_all_rows(send, send_rows, recv_rows, self.group)
-        parts, at = {}, 0
+        got = all_to_all_rows(send.view(G * cap * m, 4), [cap * m] * G, [cap * m] * G, self.group).view(G, cap, m, 4)
+        parts = {}
         for s in range(G):
+            slot = 0
             for beta in range(4 * s, 4 * s + 4):
                 if beta < 3 * G and beta % G == g:
-                    parts[beta // G] = got[at:at + m]
-                    at += m
+                    parts[beta // G] = got[s, slot]
+                    slot += 1
         assert sorted(parts) == [0, 1, 2]
         # the tail [3n, 3n + 6) and the remainder check: block 3 G lives on rank (3 G) // 4
         owner = (3 * G) // 4

@@ -185,19 +185,45 @@ __global__ __launch_bounds__(TPB) void prep_bins_kernel(const uint32_t* bin_tota
 }
 
 // entry = low bucket bits << 32 | sign << 31 | table index (window * srs_n + i)
+//
+// Write combining in pairs (round 4; measured, NOT the default).  A chunk leaves ~26 entries in each of 2048 bins, and
+// every scattered 8-byte store costs a 32-byte sector by the time its line leaves the L2 (WRITE_SIZE 379 MB for 109 MB
+// of entries, profiles/r03_pmc.csv).  With KZG_PREP_PAIR=1 entries leave in PAIRS: a bin has one 8-byte slot in LDS; an
+// entry is either deposited in the empty slot or takes the entry waiting there (compare-and-swap on the slot, no lane
+// ever waits for another) and the two go out as ONE 16-byte store at two consecutive positions of the bin; what is
+// left in the slots when a sweep ends is stored singly.  16 KiB of slots + 8 KiB of cursors fit beside the accumulate
+// workgroups.  Result (profiles/r04_scatter_pair_ab.txt, one box, alternating, bench.py --mode batch --steps 30):
+// WRITE_SIZE 378 -> 302 MB per commit (a 16-byte store still costs a sector, two when it straddles one), partition 1
+// alone 0.169 -> 0.188-0.195 ms (two LDS compare-and-swaps per entry), commits/s 462.1 / 464.1 with pairs against
+// 463.4 / 463.3 without: the pipeline does not notice 76 MB of writes, so the plain scatter stays.
+#ifndef KZG_PREP_PAIR
+#define KZG_PREP_PAIR 0
+#endif
+// two entries at p[0], p[1] as one 16-byte store (p is 8-byte aligned; gfx950 global stores need dword alignment only)
+__device__ __forceinline__ void store_pair(uint64_t* p, unsigned long long a, unsigned long long b) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(8)));
+  u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+  *reinterpret_cast<u32x4*>(p) = v;
+}
 template <int WB, int LOBV>
 __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scalars, uint32_t n, uint32_t srs_n,
                                                             uint32_t nchunk, const uint32_t* hist1,
                                                             const uint32_t* bin_start, uint64_t* ent) {
   using P = PW<WB, LOBV>;
+  constexpr bool PAIR = KZG_PREP_PAIR && P::NBIN <= 2048;
+  constexpr unsigned long long EMPTY = ~0ull;             // a real entry's upper word is a bucket index < BPB
   side_priority();
   __shared__ uint32_t cur[P::NBIN];
+  __shared__ unsigned long long slot[PAIR ? P::NBIN : 1];
   const uint32_t chunk = blockIdx.x;
-  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + chunk];
+  for (uint32_t b = threadIdx.x; b < P::NBIN; b += TPB) {
+    cur[b] = bin_start[b] + hist1[(size_t)b * nchunk + chunk];
+    if (PAIR) slot[b] = EMPTY;
+  }
   __syncthreads();
   const uint32_t base = chunk * CH1;
   // the chunk is walked once per range of NBIN / SWEEPS bins, so that a workgroup has fewer runs open at a time and
-  // more of its 8-byte stores meet in L2 before their line leaves (its scalars come from L2 after the first walk; the
+  // more of its stores meet in L2 before their line leaves (its scalars come from L2 after the first walk; the
   // digits are extracted again)
   for (uint32_t sweep = 0; sweep < SWEEPS; ++sweep) {
     const uint32_t b_lo = sweep * (P::NBIN / SWEEPS), b_hi = b_lo + P::NBIN / SWEEPS;
@@ -207,9 +233,34 @@ __global__ __launch_bounds__(TPB) void prep_scatter1_kernel(const uint32_t* scal
         for_each_digit<WB>(scalars, i, [&](uint32_t j, uint32_t key, uint32_t neg) {
           const uint32_t bin = key >> P::LOB;
           if (SWEEPS > 1 && (bin < b_lo || bin >= b_hi)) return;
-          const uint32_t pos = atomicAdd(&cur[bin], 1u);
-          ent[pos] = ((uint64_t)(key & (P::BPB - 1)) << 32) | (uint64_t)((j * srs_n + i) | (neg << 31));
+          const unsigned long long mine =
+              ((unsigned long long)(key & (P::BPB - 1)) << 32) | (unsigned long long)((j * srs_n + i) | (neg << 31));
+          if constexpr (PAIR) {
+            for (;;) {
+              const unsigned long long seen = atomicCAS(&slot[bin], EMPTY, mine);
+              if (seen == EMPTY) break;                                       // deposited: a later entry takes it along
+              if (atomicCAS(&slot[bin], seen, EMPTY) == seen) {               // took the waiting entry: the pair leaves
+                const uint32_t pos = atomicAdd(&cur[bin], 2u);
+                store_pair(ent + pos, seen, mine);
+                break;
+              }
+            }
+          } else {
+            const uint32_t pos = atomicAdd(&cur[bin], 1u);
+            ent[pos] = mine;
+          }
         });
+    }
+    if constexpr (PAIR) {     // singles of this sweep's bins
+      __syncthreads();
+      for (uint32_t b = b_lo + threadIdx.x; b < b_hi; b += TPB) {
+        const unsigned long long e = slot[b];
+        if (e != EMPTY) {
+          ent[atomicAdd(&cur[b], 1u)] = e;
+          slot[b] = EMPTY;
+        }
+      }
+      __syncthreads();
     }
   }
 }

@@ -2,7 +2,8 @@
 # A/B timing of library variants built with KZG_BUILD_DIR=ab/<name> (same box, back to back).
 #   tools/ab_bench.sh name1 name2 ...    -> gpurun_out/ab_<name>.json
 for v in "$@"; do
-  KZG_MI355X_LIB=$PWD/ab/$v/libkzg_mi355x.so python bench.py --mode batch --no-cpu-baseline --steps 30 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || echo "FAILED $v"
+  if [ "$v" = tree ]; then unset KZG_MI355X_LIB; else export KZG_MI355X_LIB=$PWD/ab/$v/libkzg_mi355x.so; fi
+  python bench.py --mode batch --no-cpu-baseline --steps 30 > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || echo "FAILED $v"
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]

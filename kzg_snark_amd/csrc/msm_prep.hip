@@ -14,7 +14,10 @@
 //     row_scan    per bin: exclusive prefix over chunks;  bins: bin starts, chunk list for step 2
 //     scatter1    digits again -> 8-byte entries (low bucket bits | table index, sign) into the bin
 //   partition 2   (one segment per bin)
-//     binsort     a bin of <= STAGE_CAP entries (every bin, with uniform scalars) is sorted by ONE workgroup: LDS
+//     binsort     a bin of <= STAGE_CAP entries (with uniform scalars: every bin the twelve full windows fill alone,
+//                 12 n / NBIN = 6.1 K entries at 2^20; the short TOP window -- bits 240..254, 13-15 significant bits --
+//                 adds n / 32 .. n / 128 entries to each of the lowest 32 .. 128 bins, which therefore outgrow the
+//                 stage and take the chunked kernels below: ~1/13 of the entries) is sorted by ONE workgroup: LDS
 //                 histogram over its BPB buckets -> bstart[]; ranks by LDS atomics; the table indices are placed in
 //                 an LDS stage of the bin's size and leave as one contiguous, fully coalesced run -- the HBM write
 //                 is the payload (round 2 scattered 4-byte elements to 1024 open runs per workgroup, which the L2
@@ -607,10 +610,13 @@ int prep_enqueue_t(Ctx* c, hipStream_t sp, const uint32_t* d_scalars, uint32_t n
 // within the sort stage, up to 8192 (the partition-1 histograms of a workgroup live in LDS: 32 KiB at 8192 bins).
 static int lob_for(uint32_t n, int win_bits) {
   if (win_bits != 20) return 8;
+  // the bins that only the full windows fill (all but the lowest few dozen) must fit the bin sort's stage: their mean
+  // m / NBIN (m = entries of all 13 windows: an upper bound of what the 12 full ones put there) + 4 sigma of the 2^20
+  // case; the bins the short top window overloads take the chunked kernels whatever the bin count
   const uint64_t m = (uint64_t)n * PW<20>::NWIN;
   for (int lob = 8; lob > 6; --lob)
-    if (m / (PW<20>::NB >> lob) + 4 * 82 <= STAGE_CAP) return lob;     // mean + 4 sigma of the 2^20 case as margin
-  return m / (PW<20>::NB >> 8) <= STAGE_CAP ? 8 : 6;
+    if (m / (PW<20>::NB >> lob) + 4 * 82 <= STAGE_CAP) return lob;
+  return 6;
 }
 
 size_t msm_prep_workspace_bytes(uint32_t n, int win_bits) {

@@ -21,7 +21,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = random.Random(seed)
 rs = np.random.RandomState(seed)
 t_end = time.time() + budget
-stats = {"ntt": 0, "ragged": 0, "commit": 0, "open": 0}
+stats = {"ntt": 0, "ragged": 0, "commit": 0, "open": 0, "open_shard": 0}
 keys = {}
 
 
@@ -52,7 +52,7 @@ while time.time() < t_end:
     cv = O.curve(curve)
     r = cv.r
     ctx = N.get_context(curve)
-    what = rng.choice(["ntt", "ntt", "ragged", "commit", "commit", "open"])
+    what = rng.choice(["ntt", "ntt", "ragged", "commit", "commit", "open", "open", "open_shard"])
     if what == "ntt":
         log_n = rng.randrange(1, 17)
         n = 1 << log_n
@@ -100,8 +100,54 @@ while time.time() < t_end:
                 want = O.normalize(O.multiply(g, O.poly_eval(coeffs, tau, r), cv), cv) if coeffs else None
                 got = None if inf[i] else tuple(N.limbs_to_ints(xy[i].reshape(2, L)))
                 assert got == want, ("commit", curve, key_n, stride, lens, i)
+        elif what == "open_shard":
+            # one polynomial set cut into G contiguous coefficient ranges, each opened as a shard (slice evaluation,
+            # carry, quotient slice against key points lo-1 ..): the partial proofs add up to the trapdoor value
+            import torch
+            k = rng.randrange(1, 8)
+            n = rng.randrange(8, min(key_n, 30000) + 1)
+            G = rng.randrange(1, 5)
+            cuts = sorted(rng.sample(range(1, n), min(G - 1, n - 1)))
+            bounds = [0] + cuts + [n]
+            arr = np.zeros((k, n, 4), dtype=np.uint64)
+            polys = []
+            for i in range(k):
+                arr[i] = scalars(n, r, rng.choice(["uniform", "small", "near_r"]))
+                polys.append(N.limbs_to_ints(arr[i]))
+            z, xi = rng.choice([0, 1, r - 1, rng.randrange(r)]), rng.choice([1, rng.randrange(r)])
+            if z == tau:
+                continue
+            ctx.set_tuning("open_tile_threads", rng.choice([0, 128, 256]))
+            ctx.set_tuning("open_direct_tiles", rng.choice([0, 0, 1, 2]))
+            zw, xw = N.int_to_words(z), N.int_to_words(xi)
+            H, acc, ev0 = [], O.Z1(), None
+            shards = []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                t = torch.from_numpy(np.ascontiguousarray(arr[:, lo:hi]).view(np.int64)).cuda()
+                H.append(N.limbs_to_ints(ctx.open_shard_begin(t.data_ptr(), [hi - lo] * k, hi - lo, zw, xw).reshape(1, 4))[0])
+                shards.append((lo, hi))
+            for gi, (lo, hi) in enumerate(shards):
+                carry = sum(H[h] * pow(z, shards[h][0] - hi, r) for h in range(gi + 1, len(shards))) % r
+                t = torch.from_numpy(np.ascontiguousarray(arr[:, lo:hi]).view(np.int64)).cuda()
+                ctx.open_shard_begin(t.data_ptr(), [hi - lo] * k, hi - lo, zw, xw)        # a context holds one slice
+                start = 0 if gi == 0 else lo - 1
+                cnt = hi - 1 - start                    # 0: a first slice of one coefficient commits nothing, but still
+                ks = ctx.srs_generate(N.int_to_words(tau), max(cnt, 1), start=start)      # reports P(z)
+                xy, inf, ev = ctx.open_shard_finish(ks, zw, N.int_to_words(carry), gi == 0)
+                ks.close()
+                if gi == 0:
+                    ev0 = N.limbs_to_ints(ev.reshape(1, 4))[0]
+                if not inf[0]:
+                    acc = O.add(acc, O.from_affine(tuple(N.limbs_to_ints(xy.reshape(2, L)))), cv)
+            ctx.set_tuning("open_tile_threads", 0)
+            ctx.set_tuning("open_direct_tiles", 0)
+            comb = O.combine(polys, xi, r)
+            assert ev0 == O.poly_eval(comb, z, r), ("open_shard eval", curve, n, bounds)
+            assert O.normalize(acc, cv) == O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv), ("open_shard", curve, n, bounds, z)
         else:
-            k = rng.randrange(1, 9)
+            k = rng.choice([rng.randrange(1, 9), rng.randrange(9, 21)])
+            ctx.set_tuning("open_tile_threads", rng.choice([0, 128, 256]))
+            ctx.set_tuning("open_direct_tiles", rng.choice([0, 0, 1, 3]))
             stride = rng.randrange(2, min(key_n, 20000) + 1)
             lens = [rng.randrange(1, stride + 1) for _ in range(k)]
             arr = np.zeros((k, stride, 4), dtype=np.uint64)
@@ -118,5 +164,7 @@ while time.time() < t_end:
             want = O.normalize(O.open_trapdoor(polys, z, xi, tau, cv), cv)
             got = None if inf[0] else tuple(N.limbs_to_ints(xy.reshape(2, L)))
             assert got == want, ("open", curve, key_n, stride, lens, z, xi)
+            ctx.set_tuning("open_tile_threads", 0)
+            ctx.set_tuning("open_direct_tiles", 0)
     stats[what] += 1
 print("fuzz ok:", stats, "seed", seed)

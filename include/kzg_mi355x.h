@@ -207,6 +207,13 @@ int kzg_open_shard_begin(kzg_ctx* ctx, const void* d_polys, const size_t* lens, 
 int kzg_open_shard_finish(kzg_ctx* ctx, const kzg_srs* srs, const uint64_t z[4], const uint64_t carry[4],
                           int first_rank, uint64_t* out_xy, uint8_t* out_inf, uint64_t* eval_out);
 
+/* Sum of n affine G1 points, on the HOST (no context, no GPU): what every rank does with the partial commitments /
+ * partial opening proofs the others computed over their coefficient ranges -- the group law is not an RCCL reduction
+ * operator, so the partial points are all-gathered as 97-byte records and added here (one inversion per sum).
+ * xy: n x 2*FP_LIMBS canonical limbs; inf: n flags or NULL; KZG_ERR_ARG for a coordinate >= p or a point off the
+ * curve.  Replaces the running kzg.add of kzg.py:116 over the ranks' results. */
+int kzg_g1_sum(int curve_id, const uint64_t* xy, const uint8_t* inf, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
 /* ---- device vector / polynomial primitives over Fr ------------------------------------------------
  * What the reference's callers do with Sage's dense polynomials between the transforms and the
  * commitments (plonk/prover.py:243-316: accumulator ratios, products, division by Z_H on a coset),

@@ -73,6 +73,7 @@ SIGNATURES = {
     "kzg_prof_read": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]),
     "kzg_open_device_async": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
+    "kzg_g1_sum": (ctypes.c_int, [ctypes.c_int, _vp, _vp, ctypes.c_size_t, _vp, _vp]),
     "kzg_open_device": (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_size_t, ctypes.c_size_t, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -417,6 +418,27 @@ class Srs:
             self.close()
         except Exception:
             pass
+
+
+def g1_sum(curve_type, points):
+    """Sum of G1 points given as facade tuples (x, y, 1) / (1, 1, 0), on the host in the library's C++ (kzg_g1_sum):
+    microseconds per point where the pure-Python group law takes tens -- the add-up of the ranks' partial results."""
+    cid = CURVE_IDS[curve_type]
+    L = lib().kzg_fp_limbs(cid)
+    n = len(points)
+    inf = np.array([1 if int(p[2]) == 0 else 0 for p in points], dtype=np.uint8)
+    coords = []
+    for p, f in zip(points, inf):
+        coords += [0, 0] if f else [int(p[0]), int(p[1])]
+    xy = ints_to_limbs(coords, L).reshape(n, 2 * L) if n else np.zeros((0, 2 * L), dtype=np.uint64)
+    out_xy, out_inf = np.zeros(2 * L, dtype=np.uint64), np.zeros(1, dtype=np.uint8)
+    rc = lib().kzg_g1_sum(cid, _as_vp(np.ascontiguousarray(xy)), _as_vp(inf), n, _as_vp(out_xy), _as_vp(out_inf))
+    if rc != 0:
+        raise NativeError(rc, "kzg_g1_sum: a coordinate is not reduced or a point is not on the curve")
+    if out_inf[0]:
+        return (1, 1, 0)
+    v = limbs_to_ints(out_xy.reshape(2, L))
+    return (v[0], v[1], 1)
 
 
 _contexts = {}

@@ -1,5 +1,6 @@
 // api.hip -- the extern "C" surface of libkzg_mi355x.so (include/kzg_mi355x.h).
 #include "internal.h"
+#include "ec.h"
 #include "msm.h"
 #include "../../include/kzg_mi355x.h"
 #include <cstdio>
@@ -68,9 +69,56 @@ int ensure_buf(Ctx* c, DevBuf& b, size_t bytes) {
 
 }  // namespace kzg
 
+namespace kzg {
+// sum of n affine points on the HOST (XYZZ accumulator, mixed additions of ec.h -- exact for O, P + P, P - P --, one
+// inversion at the end): the "reduce" of partial MSM results that RCCL has no operator for
+template <class C>
+static int g1_sum_t(const uint64_t* xy, const uint8_t* inf, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+  using F = typename C::Fp;
+  using Fd = Field<F>;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(xy);
+  XYZZ<C> acc = Ec<C>::infinity();
+  for (size_t i = 0; i < n; ++i) {
+    if (inf && inf[i]) continue;
+    const Fe<F> x = Fd::from_words(w + i * 2 * F::NW), y = Fd::from_words(w + i * 2 * F::NW + F::NW);
+    // coordinates must be canonical field elements of a point on the curve
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t* q = w + i * 2 * F::NW + half * F::NW;
+      bool below = false;
+      for (int k = F::NW - 1; k >= 0 && !below; --k) {
+        if (q[k] < F::PW[k]) below = true;
+        else if (q[k] > F::PW[k]) return KZG_ERR_ARG;
+      }
+      if (!below) return KZG_ERR_ARG;
+    }
+    const Fe<F> xm = Fd::reduce(Fd::to_mont(x)), ym = Fd::reduce(Fd::to_mont(y));
+    if (!Ec<C>::on_curve(xm, ym)) return KZG_ERR_ARG;
+    acc = Ec<C>::madd(acc, xm, ym);
+  }
+  const Affine<C> a = Ec<C>::to_affine(acc);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out_xy);
+  if (a.inf) {
+    memset(o, 0, 2 * F::NW * 4);
+    *out_inf = 1;
+    return KZG_OK;
+  }
+  Fd::to_words(Fd::from_mont(a.x), o);
+  Fd::to_words(Fd::from_mont(a.y), o + F::NW);
+  *out_inf = 0;
+  return KZG_OK;
+}
+}  // namespace kzg
+
 using namespace kzg;
 
 extern "C" {
+
+int kzg_g1_sum(int curve_id, const uint64_t* xy, const uint8_t* inf, size_t n, uint64_t* out_xy, uint8_t* out_inf) {
+  if ((n && !xy) || !out_xy || !out_inf) return KZG_ERR_ARG;
+  if (curve_id == KZG_CURVE_BN254) return g1_sum_t<Bn254>(xy, inf, n, out_xy, out_inf);
+  if (curve_id == KZG_CURVE_BLS12_381) return g1_sum_t<Bls12_381>(xy, inf, n, out_xy, out_inf);
+  return KZG_ERR_ARG;
+}
 
 int kzg_abi_version(void) { return 1; }
 

@@ -269,15 +269,21 @@ class ShardedProver:
         handle = be.commit_begin(shard, [self._with_tail(p) for p in polys])
         return handle
 
+    def _sum_points(self, pts):
+        """the ranks' partial results added up: the library's host group law (kzg_g1_sum, one inversion per sum)"""
+        try:
+            return _native.g1_sum(self.kzg.curve_type, pts)
+        except _native.NativeUnavailable:
+            acc = self.kzg.Z1
+            for p in pts:
+                acc = self.kzg.add(acc, p)
+            return acc
+
     def _commit_collect(self, handle, k):
-        kzg = self.kzg
         parts = self.be.commit_end(handle)
         blobs = self._gather(b"".join(pack_point(p) for p in parts))
-        out = [kzg.Z1] * k
-        for blob in blobs:
-            for i in range(k):
-                out[i] = kzg.add(out[i], unpack_point(blob[i * POINT_BYTES:(i + 1) * POINT_BYTES]))
-        return out
+        return [self._sum_points([unpack_point(blob[i * POINT_BYTES:(i + 1) * POINT_BYTES]) for blob in blobs])
+                for i in range(k)]
 
     def _evals(self, pairs, n):
         """[(sharded polynomial, point)] -> values: Horner over the local range times z^lo, tails on the host, one gather"""
@@ -349,10 +355,7 @@ class ShardedProver:
         hi = (g + 1) * m + (TAIL if g == G - 1 else 0)
         carry = sum(H[h] * pow(int(z), h * m - hi, r) for h in range(g + 1, G)) % r
         part, _ = be.open_finish(oshard, z, carry, g == 0)
-        acc = kzg.Z1
-        for blob in self._gather(pack_point(part)):
-            acc = kzg.add(acc, unpack_point(blob))
-        return acc
+        return self._sum_points([unpack_point(blob) for blob in self._gather(pack_point(part))])
 
     # ---- the proof
     def prove(self, ipk, x, w, blinders=None, trace=None):

@@ -440,7 +440,7 @@ def section_range(env, log_n=None, steps=None):
         xy, inf, ev = ctx.open_shard_finish(oshard, zw, nat.int_to_words(carry), first)
         return env.point(xy, inf[0]), (nat.limbs_to_ints(ev.reshape(1, 4))[0] if first else None)
 
-    dc = DistributedCommitter(commit_fn, kzg.add, kzg.Z1)
+    dc = DistributedCommitter(commit_fn, kzg.add, kzg.Z1, sum_fn=lambda pts: nat.g1_sum(args.curve, pts))
     import numpy as np
     c_xy, c_inf = np.zeros((1, 2 * ctx.fp_limbs), dtype=np.uint64), np.zeros(1, dtype=np.uint8)
 

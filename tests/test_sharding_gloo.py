@@ -87,6 +87,11 @@ def _worker(rank, world, port, q):
         dc2 = DistributedCommitter(lambda ps: [to_pt(c) for c in O.commit(shard_ck, ps, cv)], G.add, G.Z)
         got = dc2.commit_range(p[lo:hi])
         assert got == to_pt(O.commit(full_ck, [p], cv)[0]), "range mode"
+        # the same with the partial points added by the library's host group law (kzg_g1_sum) instead of one by one
+        from kzg_snark_amd import _native
+        dc3 = DistributedCommitter(lambda ps: [to_pt(c) for c in O.commit(shard_ck, ps, cv)], G.add, G.Z,
+                                   sum_fn=lambda pts: _native.g1_sum("bn254", pts))
+        assert dc3.commit_range(p[lo:hi]) == got, "range mode, sum_fn"
         assert got == to_pt(O.commit_trapdoor(p, tau, cv))
 
         # range-mode open: slice evaluation, carry exchange, quotient slice against a key shard that

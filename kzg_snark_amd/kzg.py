@@ -278,46 +278,51 @@ class KZG:
             raise
         return self._points(xy, inf)[0]
 
+    # ---- verification (host).  Both checks rest on one folded claim per opening:
+    #      F = sum_i xi^(i+1) (C_i - v_i G1) commits to sum_i xi^(i+1) (p_i - v_i), which (X - z) divides iff the v_i are
+    #      the values at z; the proof pi commits to the quotient, so  e(F, G2) = e(pi, (tau - z) G2).
+    def _sum_g1(self, points):
+        try:
+            return _native.g1_sum(self.curve_type, points)            # the library's host group law
+        except _native.NativeUnavailable:
+            total = self.Z1
+            for pt in points:
+                total = self.add(total, pt)
+            return total
+
+    def _folded_claim(self, commitments, evaluations, xi):
+        """F above.  Weights are xi^(i+1) by position in EACH list, as the reference's two loops have it
+        (kzg.py:187-194; its batch form indexes the evaluations by the commitments' positions, kzg.py:262-266)."""
+        weight, parts = xi, []
+        for C in commitments:
+            parts.append(self.multiply(C, int(weight)))
+            weight *= xi
+        weight, value = xi, self.Fq(0)
+        for v in evaluations:
+            value += weight * self.Fq(v)
+            weight *= xi
+        parts.append(self.multiply(self.G1, int(-value)))
+        return self._sum_g1(parts)
+
     def check(self, rk, commitments, z, evaluations, proof, xi):
-        """kzg.py:161-211 (host: O(#commitments) scalar-muls and two pairings)."""
-        tau_G2 = rk
-        z = self.Fq(z)
-        xi = self.Fq(xi)
-        combined_commitment = self.Z1
-        for i, comm in enumerate(commitments):
-            combined_commitment = self.add(combined_commitment, self.multiply(comm, int(xi ** (i + 1))))
-        combined_evaluation = self.Fq(0)
-        for i, eval_i in enumerate(evaluations):
-            combined_evaluation += xi ** (i + 1) * self.Fq(eval_i)
-        v_G1 = self.multiply(self.G1, int(combined_evaluation))
-        C_minus_v = self.add(combined_commitment, self.neg(v_G1))
-        z_G2 = self.multiply(self.G2, int(z))
-        tauG2_minus_z = self.add(tau_G2, self.neg(z_G2))
-        return self.pairing(self.G2, C_minus_v) == self.pairing(tauG2_minus_z, proof)
+        """kzg.py:161-211: two pairings, e(F, G2) against e(pi, tau G2 - z G2)."""
+        z, xi = self.Fq(z), self.Fq(xi)
+        F = self._folded_claim(commitments, evaluations, xi)
+        shifted_key = self.add(rk, self.neg(self.multiply(self.G2, int(z))))
+        return self.pairing(self.G2, F) == self.pairing(shifted_key, proof)
 
     def batch_check(self, rk, commitments_list, z_list, evaluations_list, proof_list, xi_list, r=None):
-        """kzg.py:213-288."""
-        tau_G2 = rk
-        if r is None:
-            r = self.Fq.random_element()
-        r = self.Fq(r)
-        left_acc = self.Z1
-        right_acc = self.Z1
-        for i, (commitments, z, evaluations, proof, xi) in enumerate(
-                zip(commitments_list, z_list, evaluations_list, proof_list, xi_list)):
-            z = self.Fq(z)
-            xi = self.Fq(xi)
-            combined_commitment = self.Z1
-            combined_evaluation = self.Fq(0)
-            for j, comm in enumerate(commitments):
-                xi_power = xi ** (j + 1)
-                combined_commitment = self.add(combined_commitment, self.multiply(comm, int(xi_power)))
-                combined_evaluation += xi_power * self.Fq(evaluations[j])
-            v_G1 = self.multiply(self.G1, int(combined_evaluation))
-            C_minus_v = self.add(combined_commitment, self.neg(v_G1))
-            z_pi = self.multiply(proof, int(z))
-            term_left = self.add(C_minus_v, z_pi)
-            r_power = int(r ** (i + 1))
-            left_acc = self.add(left_acc, self.multiply(term_left, r_power))
-            right_acc = self.add(right_acc, self.multiply(proof, r_power))
-        return self.pairing(self.G2, left_acc) == self.pairing(tau_G2, right_acc)
+        """kzg.py:213-288: the openings' equations e(F_i + z_i pi_i, G2) = e(pi_i, tau G2) added up with weights
+        rho^(i+1) (rho = `r`, sampled when not given: kzg.py:244-245) -- two pairings for any number of openings."""
+        rho = self.Fq(self.Fq.random_element() if r is None else r)
+        weight, lhs, rhs = rho, [], []
+        for commitments, z, evaluations, proof, xi in zip(commitments_list, z_list, evaluations_list, proof_list,
+                                                          xi_list):
+            evaluations = list(evaluations)
+            if len(evaluations) < len(commitments):
+                raise IndexError("list index out of range")              # kzg.py:266 reads evaluations[j] per commitment
+            F = self._folded_claim(commitments, evaluations[:len(commitments)], self.Fq(xi))
+            lhs.append(self.multiply(self.add(F, self.multiply(proof, int(self.Fq(z)))), int(weight)))
+            rhs.append(self.multiply(proof, int(weight)))
+            weight *= rho
+        return self.pairing(self.G2, self._sum_g1(lhs)) == self.pairing(rk, self._sum_g1(rhs))

@@ -6,8 +6,8 @@
 // Division by (X - z) is synthetic division: with S_j = sum_{i>=j} c_i z^(i-j)
 // (suffix Horner values, S_j = c_j + z*S_{j+1}) the quotient is q_{j-1} = S_j for
 // j >= 1 and combined(z) = S_0.  The recurrence is evaluated in two tile passes (below,
-// "The opening's scan as TWO tile passes"); the level-by-level chunk collapse of rounds 1-3
-// survives in kzg_fr_poly_eval.  The MSM of the quotient (msm.hip) dominates open() by far.
+// "The opening's scan as TWO tile passes"); kzg_fr_poly_eval is the first of them without its stores.
+// The MSM of the quotient (msm.hip) dominates open() by far.
 // These kernels are bound by dependent Horner chains and by memory latency, not by instruction issue: the chain pin of
 // field.h (an asm volatile per multiply-add) would only keep the scheduler from hoisting the next loads.
 #define KZG_NO_CHAIN_PIN 1
@@ -108,23 +108,6 @@ __global__ void lincomb_kernel(LincombArgs a, uint32_t* out, uint32_t n) {
     acc = i0 ? Fd::add(acc, part) : part;
   }
   store_words<F>(out + (size_t)t * 8, acc);
-}
-
-// bottom-up: h[t] = sum_{j in chunk t} c_j * z^(j - t*SC)
-template <class F, bool WORDS_IN>
-__global__ void chunk_eval_kernel(const uint32_t* in, uint32_t m, FrArg zpow, uint32_t* h) {
-  using Fd = Field<F>;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j0 = t * SC;
-  if (j0 >= m) return;
-  const uint32_t j1 = min(j0 + SC, m);
-  const Fe<F> z = load_limbs<F>(zpow.l);
-  Fe<F> acc = Fd::zero();
-  for (uint32_t j = j1; j-- > j0;) {
-    const Fe<F> c = WORDS_IN ? load_words<F>(in + (size_t)j * 8) : load_limbs<F>(in + (size_t)j * F::N);
-    acc = Fd::add(c, Fd::mul(acc, z));
-  }
-  store_limbs<F>(h + (size_t)t * F::N, acc);
 }
 
 __global__ void any_nonzero_kernel(const uint32_t* words, size_t from_elem, size_t to_elem, uint32_t* flag) {
@@ -239,7 +222,8 @@ __device__ __forceinline__ Fe<F> pow_from_generators(const uint32_t* g, uint32_t
 // TB chunks (T = 8 TB coefficients) per tile, TK = T / ITER threads per workgroup: the kernel waits for memory, so the
 // coefficients of a tile are spread over MORE threads than the fill uses (2 waves per SIMD at one thread per chunk:
 // 77 us for the 2^20 x 6 combination; profiles/r04a_open_kernel_stats.csv), each taking ITER strided elements.
-template <class F, uint32_t TB, uint32_t ITER>
+// STORE = false: the aggregates alone (kzg_fr_poly_eval: nothing but H and the tables is written).
+template <class F, uint32_t TB, uint32_t ITER, bool STORE = true>
 __global__ __launch_bounds__(TB * SC / ITER) void tile_combine_kernel(TileLincomb a, TileScanArgs ts, uint32_t* comb,
                                                                       uint32_t n, uint32_t ntiles, uint32_t* G,
                                                                       uint32_t* H, uint32_t* zinv, uint32_t* W) {
@@ -282,7 +266,7 @@ __global__ __launch_bounds__(TB * SC / ITER) void tile_combine_kernel(TileLincom
         const Fe<F> part = dot_upto<F>(cnt, c, x);
         acc = i0 ? Fd::add(acc, part) : part;
       }
-      store_words<F>(comb + (size_t)t * 8, acc);
+      if (STORE) store_words<F>(comb + (size_t)t * 8, acc);
     }
     const Fe<F> e = Fd::mul(acc, zr);                                         // 0 beyond the end
     Fe<F> s;
@@ -296,7 +280,7 @@ __global__ __launch_bounds__(TB * SC / ITER) void tile_combine_kernel(TileLincom
     const Fe<F> hq = Fd::reduce_wide(Fd::carry(load_limbs<F>(hs + tid * F::N)));
     const Fe<F> zq = Fd::mul(load_limbs<F>(ts.zq_lo + (tid & 15) * F::N), load_limbs<F>(ts.zq_hi + (tid >> 4) * F::N));
     g = Fd::mul(hq, zq);
-    store_limbs<F>(G + ((size_t)b * TB + tid) * F::N, g);
+    if (STORE) store_limbs<F>(G + ((size_t)b * TB + tid) * F::N, g);
   }
   const Fe<F> hb = block_sum<F, TK>(g, red);
   if (tid == 0) store_limbs<F>(H + (size_t)b * F::N, hb);
@@ -468,7 +452,8 @@ static uint32_t open_tile_threads(Ctx* c) {
 }
 
 template <class F>
-int tile_plan(Ctx* c, size_t n, const uint32_t* z_words, uint32_t tb, TilePlan<F>* p) {
+int tile_plan(Ctx* c, size_t n, const uint32_t* z_words, uint32_t tb, TilePlan<F>* p, DevBuf* buf = nullptr,
+              bool with_chunks = true) {
   using Fd = Field<F>;
   const uint32_t T = tb * SC, tk = T / TILE_ITER;
   p->tb = tb;
@@ -493,11 +478,13 @@ int tile_plan(Ctx* c, size_t n, const uint32_t* z_words, uint32_t tb, TilePlan<F
   g = p->z_inv;
   for (uint32_t q = 0; q < SC_LOG; ++q) g = Fd::mul(g, g);    // z^-8
   for (uint32_t s = 0; s < 9; ++s) { memcpy(&p->ts.ginv[s * F::N], g.l, F::N * 4); g = Fd::mul(g, g); }
-  const size_t words = ((size_t)p->ntiles * tb + (p->ntiles + 1) + (p->nsuper + 1) + (tb + 1) + p->ntiles) * F::N;
-  int rc = ensure_buf(c, c->scan_tmp, words * 4);
+  const size_t chunk_words = with_chunks ? (size_t)p->ntiles * tb : 0;
+  const size_t words = (chunk_words + (p->ntiles + 1) + (p->nsuper + 1) + (tb + 1) + p->ntiles) * F::N;
+  DevBuf& b = buf ? *buf : c->scan_tmp;
+  int rc = ensure_buf(c, b, words * 4);
   if (rc) return rc;
-  p->G = static_cast<uint32_t*>(c->scan_tmp.p);
-  p->H = p->G + (size_t)p->ntiles * tb * F::N;
+  p->G = static_cast<uint32_t*>(b.p);
+  p->H = p->G + chunk_words * F::N;
   p->A = p->H + (size_t)(p->ntiles + 1) * F::N;
   p->zinv = p->A + (size_t)(p->nsuper + 1) * F::N;
   p->W = p->zinv + (size_t)(tb + 1) * F::N;
@@ -1031,49 +1018,38 @@ int vec_prefix_product_t(Ctx* c, size_t n, const uint32_t* a, uint32_t* out) {
   return KZG_OK;
 }
 
-// p(z) for a coefficient vector: the bottom-up half of the open() scan
+// p(z) for a coefficient vector: pass 1 of the opening's scan without its stores (tile aggregates only), then the
+// one-workgroup sum of the aggregates -- two launches (rounds 1-3 collapsed chunks of 8 level by level: seven)
 template <class F>
 int poly_eval_t(Ctx* c, size_t n, const uint32_t* a, const uint32_t* z_words, uint64_t* out) {
   using Fd = Field<F>;
   memset(out, 0, 32);
   if (n == 0) return KZG_OK;
-  if (n >= (1ull << 31)) return set_err(c, KZG_ERR_ARG, "vector too long");
-  std::vector<uint32_t> m{(uint32_t)n};
-  while (m.back() > 1) m.push_back((m.back() + SC - 1) / SC);
-  const size_t nl = m.size();
-  std::vector<FrArg> zp(nl);                              // z^(SC^l), passed to the kernels by value
-  {
-    Fe<F> t = Fd::to_mont(Fd::from_words(z_words));
-    for (size_t l = 0; l < nl; ++l) {
-      memcpy(zp[l].l, t.l, F::N * 4);
-      for (uint32_t q = 0; q < SC_LOG; ++q) t = Fd::mul(t, t);
-    }
-  }
-  size_t total = 0;
-  for (size_t l = 1; l < nl; ++l) total += m[l];
-  int rc;
-  if ((rc = ensure_buf(c, c->poly_tmp[2], (total + 1) * F::N * 4))) return rc;
-  uint32_t* d_h = static_cast<uint32_t*>(c->poly_tmp[2].p);
-  if (nl == 1) {     // n == 1: the value is the coefficient itself
+  if (n >= (1ull << 31) - 1) return set_err(c, KZG_ERR_ARG, "vector too long");
+  if (n == 1 || words_are_zero(z_words)) {      // the constant coefficient
     KZG_HIP(c, hipMemcpyAsync(out, a, 32, hipMemcpyDeviceToHost, c->stream));
     KZG_HIP(c, hipStreamSynchronize(c->stream));
     return KZG_OK;
   }
-  std::vector<uint32_t*> hp(nl, nullptr);
-  { uint32_t* x = d_h; for (size_t l = 1; l < nl; ++l) { hp[l] = x; x += (size_t)m[l] * F::N; } }
-  hipLaunchKernelGGL((chunk_eval_kernel<F, true>), dim3((m[1] + 127) / 128), dim3(128), 0, c->stream, a, m[0],
-                     zp[0], hp[1]);
-  for (size_t l = 1; l + 1 < nl; ++l)
-    hipLaunchKernelGGL((chunk_eval_kernel<F, false>), dim3((m[l + 1] + 127) / 128), dim3(128), 0, c->stream, hp[l],
-                       m[l], zp[l], hp[l + 1]);
+  TilePlan<F> p;
+  int rc = tile_plan<F>(c, n, z_words, 256, &p, &c->poly_tmp[2], /*with_chunks=*/false);
+  if (rc) return rc;
+  if ((rc = ensure_buf(c, c->poly_tmp[3], 32))) return rc;
+  uint32_t* d_val = static_cast<uint32_t*>(c->poly_tmp[3].p);
+  TileLincomb la{};
+  la.polys = a; la.stride = n; la.k = 1; la.lens[0] = (uint32_t)n;
+  const Fe<F> one = Fd::one();
+  memcpy(&la.xipow[0], one.l, F::N * 4);
+  hipLaunchKernelGGL((tile_combine_kernel<F, 256, TILE_ITER, false>), dim3(p.ntiles + p.ntab), dim3(256 * SC / TILE_ITER),
+                     0, c->stream, la, p.ts, (uint32_t*)nullptr, (uint32_t)n, p.ntiles, (uint32_t*)nullptr, p.H, p.zinv,
+                     p.W);
+  if (p.nsuper)
+    hipLaunchKernelGGL(tile_group_kernel<F>, dim3(p.nsuper), dim3(64), 0, c->stream, p.H, p.W, p.ntiles, p.A);
+  hipLaunchKernelGGL((tile_eval_kernel<F, 256>), dim3(1), dim3(256), 0, c->stream, p.ntiles, p.H,
+                     p.nsuper ? p.A : (const uint32_t*)nullptr, p.nsuper, p.W, d_val);
   KZG_HIP(c, hipGetLastError());
-  // the top level holds one weak-normal value (standard form): canonicalise on the host
-  uint32_t top[F::N];
-  KZG_HIP(c, hipMemcpyAsync(top, hp[nl - 1], F::N * 4, hipMemcpyDeviceToHost, c->stream));
+  KZG_HIP(c, hipMemcpyAsync(out, d_val, 32, hipMemcpyDeviceToHost, c->stream));
   KZG_HIP(c, hipStreamSynchronize(c->stream));
-  Fe<F> v;
-  memcpy(v.l, top, F::N * 4);
-  Fd::to_words(Fd::reduce(v), reinterpret_cast<uint32_t*>(out));
   return KZG_OK;
 }
 

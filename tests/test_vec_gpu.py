@@ -73,3 +73,25 @@ def test_vector_primitives(native, curve, n):
     ctx.vec_lincomb(n, [da.data_ptr(), db.data_ptr(), dc.data_ptr()], [n, n, len(c)], sc, out.data_ptr())
     ctx.synchronize()
     assert host(native, out) == [(sc[0] * a[i] + sc[1] * b[i] + sc[2] * (c[i] if i < len(c) else 0)) % r for i in range(n)]
+
+
+@pytest.mark.parametrize("curve", ["bls12_381", "bn254"])
+def test_poly_eval_at_the_tile_boundaries(native, curve):
+    """kzg_fr_poly_eval = the first tile pass of the opening's scan without its stores + the sum of the tile
+    aggregates: lengths around the chunk (8) and tile (2048) sizes and far beyond, z = 0 / 1 / r-1 / random,
+    coefficients r-1 / random, also with the aggregates of 64 tiles folded first (`open_direct_tiles` = 1: the path
+    polynomials beyond 2^21 coefficients take)."""
+    r = O.curve(curve).r
+    ctx = native.get_context(curve)
+    rng = random.Random(8)
+    try:
+        for n in (1, 2, 7, 8, 9, 2047, 2048, 2049, 4096, 100001, 300000):
+            a = [r - 1] * n if n % 2 == 0 and n < 5000 else [rng.randrange(r) for _ in range(n)]
+            da = dev(native, a)
+            for z in (0, 1, r - 1, rng.randrange(r)):
+                want = O.poly_eval(a, z, r)
+                for direct in ((0, 1) if n > 4096 else (0,)):
+                    ctx.set_tuning("open_direct_tiles", direct)
+                    assert ctx.poly_eval(n, da.data_ptr(), z) == want, (n, z, direct)
+    finally:
+        ctx.set_tuning("open_direct_tiles", 0)

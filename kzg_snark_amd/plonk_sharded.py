@@ -61,7 +61,6 @@ class GpuShardBackend:
         self.alg = alg
         self.ctx = alg.ctx
         self.r = alg.r
-        self._ops = {}
 
     # -- vectors
     def upload(self, values):
@@ -264,10 +263,9 @@ class ShardedProver:
 
     # ---- distributed pieces of the rounds
     def _commit_round(self, shard, polys):
-        """partial commitments of this rank's shards -> the full commitments on every rank (one gather)"""
-        be, kzg = self.be, self.kzg
-        handle = be.commit_begin(shard, [self._with_tail(p) for p in polys])
-        return handle
+        """queue this rank's partial commitments (its range of every polynomial, the tail on the last rank) on the
+        commit pipeline; _commit_collect gathers and adds the ranks' partial points"""
+        return self.be.commit_begin(shard, [self._with_tail(p) for p in polys])
 
     def _sum_points(self, pts):
         """the ranks' partial results added up: the library's host group law (kzg_g1_sum, one inversion per sum)"""
@@ -349,7 +347,7 @@ class ShardedProver:
 
     def _open(self, oshard, polys, z, xi, n):
         """kzg.py:122-159 on range shards: slice evaluations, carries, partial proofs (two gathers)"""
-        be, kzg, r, G, g = self.be, self.kzg, self.kzg.curve_order, self.world, self.rank
+        be, r, G, g = self.be, self.kzg.curve_order, self.world, self.rank
         m = n // G
         H = [row[0] for row in self._gather_ints([be.open_begin([self._with_tail(p) for p in polys], z, xi)])]
         hi = (g + 1) * m + (TAIL if g == G - 1 else 0)

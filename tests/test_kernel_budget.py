@@ -63,3 +63,19 @@ def test_prep_kernels_are_small(kernels):
         cap, regs = (31 * 1024, 96) if "binsort" in name else \
                     (33 * 1024, 64) if ("prep_count1" in name or "prep_scatter1" in name) else (9 * 1024, 64)
         assert vgpr <= regs and lds <= cap and scratch == 0, name
+
+
+def test_opening_tiles_fit_beside_the_accumulate_kernel(kernels):
+    """While an accumulate kernel is in flight the opening takes 1024-coefficient tiles (128 fill threads / 256
+    combine threads): the fill's LDS stage must fit the 46 KiB four accumulate workgroups leave on a CU, and a wave of
+    either kernel the 192 VGPRs two accumulate waves leave on a SIMD.  The 2048-coefficient tiles (alone on the GPU)
+    must leave room for two workgroups per CU."""
+    fill = sorted(rows_of(kernels, "tile_fill_kernel"), key=lambda k: k[2])
+    small, big = [k for k in fill if k[2] < 40 * 1024], [k for k in fill if k[2] >= 40 * 1024]
+    assert small and big
+    for _, vgpr, lds, scratch in small:
+        assert lds <= 46 * 1024 and vgpr <= 128 and scratch == 0
+    for _, vgpr, lds, scratch in big:
+        assert lds <= 80 * 1024 and vgpr <= 128 and scratch == 0
+    for _, vgpr, lds, scratch in rows_of(kernels, "tile_combine_kernel"):
+        assert vgpr <= 128 and lds <= 16 * 1024 and scratch == 0      # four waves per SIMD: the kernel waits for memory

@@ -78,3 +78,39 @@ def test_build_is_keyed_on_what_it_is_built_from(built, monkeypatch):
     before = build.source_hash("ntt.hip")
     monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DKZG_SOME_SWITCH=1"])
     assert build.source_hash("ntt.hip") != before                    # flags are part of the key
+
+
+def test_header_is_plain_c_and_links_from_c(built, tmp_path):
+    """The boundary is a C ABI: include/kzg_mi355x.h must compile as C99 (no C++ in the signatures) and a plain C
+    program must link against the library and call it -- here the entry points that need no GPU (version, limb
+    counts, the host-side sum of partial points with the generator added to itself and to its negative)."""
+    src = tmp_path / "abi_probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "kzg_mi355x.h"
+int main(void) {
+  if (kzg_abi_version() != 1 || kzg_fp_limbs(KZG_CURVE_BN254) != 4 || kzg_fp_limbs(KZG_CURVE_BLS12_381) != 6) return 1;
+  /* BN254 G1 generator (1, 2) and its negative (1, p - 2) */
+  uint64_t xy[16] = {1, 0, 0, 0, 2, 0, 0, 0,
+                     1, 0, 0, 0, 0x3c208c16d87cfd45ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+  uint64_t out[8]; uint8_t inf = 9;
+  if (kzg_g1_sum(KZG_CURVE_BN254, xy, NULL, 2, out, &inf) != KZG_OK || inf != 1) return 2;      /* G + (-G) = O */
+  if (kzg_g1_sum(KZG_CURVE_BN254, xy, NULL, 1, out, &inf) != KZG_OK || inf != 0 || out[0] != 1 || out[4] != 2) return 3;
+  uint64_t two[16]; memcpy(two, xy, 64); memcpy(two + 8, xy, 64);
+  if (kzg_g1_sum(KZG_CURVE_BN254, two, NULL, 2, out, &inf) != KZG_OK || inf != 0) return 4;       /* G + G = 2G */
+  if (out[0] != 0xd3c208c16d87cfd3ull || out[3] != 0x030644e72e131a02ull) return 5;               /* 2G.x (EIP-196) */
+  if (kzg_ctx_create(7, 0, NULL) != KZG_ERR_ARG) return 6;
+  puts("abi ok");
+  return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(built)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "kzg_mi355x.h")],
+                   check=True)
+    exe = tmp_path / "abi_probe"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lkzg_mi355x",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "abi ok" in out.stdout, (out.returncode, out.stdout, out.stderr[-500:])

@@ -207,17 +207,24 @@ class ShardedProver:
         return self._dom_cache[key]
 
     def _on_coset(self, sp, n, D):
-        """evaluations of a sharded polynomial on the coset K * H', |H'| = 4n, in the transposed layout"""
+        return self._on_coset_batch([sp], n, D)[0]
+
+    def _on_coset_batch(self, sps, n, D):
+        """evaluations of sharded polynomials on the coset K * H', |H'| = 4n, in the transposed layout; the batch
+        shares one set of all-to-alls"""
         be, r = self.be, self.kzg.curve_order
         m = n // self.world
         lo = self.rank * m
         log_n = n.bit_length() - 1
-        shifted = be.mul_powers(sp.local, D["K"], pow(D["K"], lo, r))               # c_i K^i, i = lo + local index
-        E = self.tf.padded_to_T(shifted, log_n, D["log4"], D["w4"])
-        if any(sp.tail):                                                            # + x^n (t0 + t1 x + t2 x^2)
-            assert len(sp.tail) <= 3
-            E = be.lincomb(E.shape[0], [(1, E)] + [(tv, D["xnx"][j]) for j, tv in enumerate(sp.tail) if tv])
-        return E
+        shifted = [be.mul_powers(sp.local, D["K"], pow(D["K"], lo, r)) for sp in sps]    # c_i K^i, i = lo + local index
+        Es = self.tf.padded_to_T_batch(shifted, log_n, D["log4"], D["w4"])
+        out = []
+        for sp, E in zip(sps, Es):
+            if any(sp.tail):                                                        # + x^n (t0 + t1 x + t2 x^2)
+                assert len(sp.tail) <= 3
+                E = be.lincomb(E.shape[0], [(1, E)] + [(tv, D["xnx"][j]) for j, tv in enumerate(sp.tail) if tv])
+            out.append(E)
+        return out
 
     def _blind(self, coeffs_local, blinders):
         """+ (b_k X^k + ..) (X^n - 1): the low coefficients live on rank 0, the high ones are the tail"""
@@ -257,7 +264,8 @@ class ShardedProver:
             lo = self.rank * m
             C = {k: SPoly(v[lo:lo + m].contiguous()) for k, v in ipk["coeffs"].items()}
             S = {k: v[lo:lo + m].contiguous() for k, v in ipk["sigma_values"].items()}
-            E = {k: self._on_coset(C[k], n, D) for k in ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3")}
+            names = ("qM", "qL", "qR", "qO", "qC", "S_sigma1", "S_sigma2", "S_sigma3")
+            E = dict(zip(names, self._on_coset_batch([C[k] for k in names], n, D)))
             cache[key] = (C, S, E)
         return cache[key]
 
@@ -415,12 +423,12 @@ class ShardedProver:
         if lo < nx:
             cnt = min(nx, lo + m) - lo
             pi_vals[:cnt] = be.upload([(-v) % r for v in x_ints[lo:lo + cnt]])
-        co = [self.tf.natural(v.clone(), log_n, g, True) for v in vals]
+        co = self.tf.natural_batch(vals + [pi_vals], log_n, g, True)                # four INTTs, one set of all-to-alls
         wires = [self._blind(co[i], [b[2 * i + 1], b[2 * i]]) for i in range(3)]
         a_c, b_c, c_c = wires
         h1 = self._commit_round(cshard, wires)
-        PI_c = SPoly(self.tf.natural(pi_vals, log_n, g, True))
-        E = {k: self._on_coset(v, n, D) for k, v in (("a", a_c), ("b", b_c), ("c", c_c), ("PI", PI_c))}
+        PI_c = SPoly(co[3])
+        E = dict(zip(("a", "b", "c", "PI"), self._on_coset_batch([a_c, b_c, c_c, PI_c], n, D)))
         E.update(E_circ)
         gate = be.add(be.add(be.mul(be.mul(E["a"], E["b"]), E["qM"]), be.mul(E["a"], E["qL"])),
                       be.add(be.mul(E["b"], E["qR"]), be.mul(E["c"], E["qO"])))

@@ -517,44 +517,94 @@ class ShardedTransforms:
         i = torch.arange((N1 // G) * N2, device=device)
         return (i % N2) * N1 + g * (N1 // G) + i // N2
 
-    # ---- natural -> natural
+    # ---- natural -> natural.  Several vectors of one domain go through ONE set of all-to-alls: their blocks for a peer
+    # travel as one message (the local passes run per vector between the exchanges)
     def natural(self, x, log_n, w, inverse):
+        return self.natural_batch([x], log_n, w, inverse)[0]
+
+    def _exchange_stacked(self, d, blocks, fresh=False):
+        """blocks: B tensors [G, ...] of one shape, block h of each meant for rank h -> what the ranks sent us, per
+        vector, [G, ...] contiguous.  One all-to-all for the whole batch.  fresh: the result must not alias the
+        caller's tensors (a one-rank exchange hands its input back; the local passes then work in place)."""
+        if len(blocks) == 1:
+            send = blocks[0].contiguous()
+            if fresh and send.data_ptr() == blocks[0].data_ptr():
+                send = send.clone()
+            return [d.exchange(send)]
+        got = d.exchange(torch.stack(blocks, dim=1).contiguous())            # [G][B][...]
+        return [got[:, b].contiguous() for b in range(len(blocks))]
+
+    def natural_batch(self, xs, log_n, w, inverse):
         n, G, g = 1 << log_n, self.world, self.rank
-        assert x.shape[0] * G == n
-        if self._distributed(log_n):
-            self.exchanges += 3
-            return self._dntt(log_n, w, inverse).transform(x, log_n, layout="natural")
-        self.exchanges += 1
-        full = all_gather_tensor(x, self.group)
-        self.full_ntt(full, w, inverse)
         m = n // G
-        return full[g * m:(g + 1) * m].clone()
+        assert all(x.shape[0] == m for x in xs)
+        if not self._distributed(log_n):
+            self.exchanges += 1
+            full = all_gather_tensor(torch.stack(xs, dim=1).contiguous(), self.group)        # [n][B][4]
+            out = []
+            for b in range(len(xs)):
+                v = full[:, b].contiguous()
+                self.full_ntt(v, w, inverse)
+                out.append(v[g * m:(g + 1) * m].clone())
+            return out
+        k1 = (log_n + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_n - k1)
+        if N1 % G or N2 % G:
+            raise ValueError("world size must divide both sides of the four-step matrix")
+        R1, W = N1 // G, N2 // G
+        d = self._dntt(log_n, w, inverse)
+        self.exchanges += 3
+        Ms = [t.view(N1, W, 4) for t in
+              self._exchange_stacked(d, [x.view(R1, G, W, 4).permute(1, 0, 2, 3) for x in xs], fresh=True)]   # rows -> columns
+        for M in Ms:
+            d.ops.columns(M, g * W)
+        recvs = self._exchange_stacked(d, [M.view(G, R1, W, 4) for M in Ms])                          # columns -> rows
+        outs = []
+        for recv in recvs:
+            out = torch.empty_like(recv)
+            d.ops.rows_exchange(recv, out, G, True)                       # [G][R1][W] over the output index
+            outs.append(out)
+        gots = self._exchange_stacked(d, outs)                             # block h: rows of rank h, our W outputs
+        return [t.view(N1, W, 4).permute(1, 0, 2).contiguous().view(W * N1, 4) for t in gots]
 
     # ---- first n entries of a zero-padded 2^log_big vector -> transposed layout
     def padded_to_T(self, x, log_n, log_big, w):
+        return self.padded_to_T_batch([x], log_n, log_big, w)[0]
+
+    def padded_to_T_batch(self, xs, log_n, log_big, w):
         n, G, g = 1 << log_n, self.world, self.rank
         m = n // G
-        assert x.shape[0] == m and log_big >= log_n
+        assert all(x.shape[0] == m for x in xs) and log_big >= log_n
         k1 = (log_big + 1) // 2
         N1, N2 = 1 << k1, 1 << (log_big - k1)
         if self._distributed(log_big) and m % N2 == 0 and N1 % G == 0:
             R1, W, Rh = N1 // G, N2 // G, m // N2                      # my rows of the N1 x N2 view: g * Rh ..
-            send = x.view(Rh, G, W, 4).permute(1, 0, 2, 3).contiguous()
             d = self._dntt(log_big, w, False)
-            got = d.exchange(send)                                     # [G][Rh][W]: rows h * Rh + r, my W columns
-            M = torch.zeros((N1, W, 4), dtype=x.dtype, device=x.device)
-            M[:G * Rh] = got.view(G * Rh, W, 4)
-            d.ops.columns(M, g * W)
-            recv = d.exchange(M.view(G, R1, W, 4))
-            out = torch.empty_like(recv)
-            d.ops.rows_exchange(recv, out, G, False)
+            gots = self._exchange_stacked(d, [x.view(Rh, G, W, 4).permute(1, 0, 2, 3) for x in xs], fresh=True)
+            Ms = []
+            for got in gots:                                           # [G][Rh][W]: rows h * Rh + r, my W columns
+                M = torch.zeros((N1, W, 4), dtype=got.dtype, device=got.device)
+                M[:G * Rh] = got.view(G * Rh, W, 4)
+                d.ops.columns(M, g * W)
+                Ms.append(M)
+            recvs = self._exchange_stacked(d, [M.view(G, R1, W, 4) for M in Ms])
+            outs = []
+            for recv in recvs:
+                out = torch.empty_like(recv)
+                d.ops.rows_exchange(recv, out, G, False)
+                outs.append(out.view(R1 * N2, 4))
             self.exchanges += 2
-            return out.view(R1 * N2, 4)
+            return outs
         self.exchanges += 1
-        full = torch.zeros((1 << log_big, 4), dtype=x.dtype, device=x.device)
-        full[:n] = all_gather_tensor(x, self.group)
-        self.full_ntt(full, w, False)
-        return full.index_select(0, self.t_index(log_big, x.device))
+        gathered = all_gather_tensor(torch.stack(xs, dim=1).contiguous(), self.group)             # [n][B][4]
+        idx = self.t_index(log_big, xs[0].device)
+        outs = []
+        for b in range(len(xs)):
+            full = torch.zeros((1 << log_big, 4), dtype=xs[0].dtype, device=xs[0].device)
+            full[:n] = gathered[:, b]
+            self.full_ntt(full, w, False)
+            outs.append(full.index_select(0, idx))
+        return outs
 
     # ---- transposed layout -> natural range (then an ordinary distributed transform)
     def T_to_natural(self, x, log_big, w, inverse):

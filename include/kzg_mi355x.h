@@ -114,6 +114,20 @@ int kzg_ntt_columns_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uin
                            uint64_t n_cols, uint64_t col_base);
 int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
                         uint64_t n_rows);
+/* The same transform taken the other way round: input in the TRANSPOSED layout (what the rows pass above leaves:
+ * row rho of the [N1][N2] matrix holds the elements b*N1 + rho, b = 0..N2-1), output in natural order --
+ *   rows_twist:    N2-point transforms along n_rows rows (global rows row_base ..), each output (rho, beta) multiplied
+ *                  by w^(rho*beta) (and by n^-1 when inverse); in place;
+ *   (all-to-all: rows -> whole columns)
+ *   columns_plain: N1-point transforms down n_cols columns of an [N1][n_cols] matrix, no twist; element (alpha, beta)
+ *                  is then X[alpha*N2 + beta]: an all-to-all back to rows gives every rank a contiguous range.
+ * Two all-to-alls instead of the four that "bring the data into range order, then transform" costs.  Unlike the
+ * passes above this pair relies on w^n = 1: w must be a primitive 2^log_n-th root of unity (KZG_ERR_ARG otherwise).
+ * Requires log_n > 12. */
+int kzg_ntt_rows_twist_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                              uint64_t n_rows, uint64_t row_base);
+int kzg_ntt_columns_plain_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                                 uint64_t n_cols);
 /* The rows half reading and writing the all-to-all buffers directly (no repacking copies):
  *   d_src  [world][n_rows][N2/world]  what the columns -> rows all-to-all delivers: block h holds
  *          columns h*N2/world .. of this rank's n_rows rows;

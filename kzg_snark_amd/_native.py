@@ -45,6 +45,8 @@ SIGNATURES = {
     "kzg_ntt_columns_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
                                               ctypes.c_uint64]),
     "kzg_ntt_rows_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64]),
+    "kzg_ntt_rows_twist_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]),
+    "kzg_ntt_columns_plain_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64]),
     "kzg_ntt_rows_exchange_device": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint32, _vp, ctypes.c_int, ctypes.c_uint64,
                                                     ctypes.c_uint32, ctypes.c_int]),
     "kzg_srs_generate_strided": (ctypes.c_int, [_vp, _vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
@@ -256,6 +258,14 @@ class Context:
     def ntt_rows_device(self, d_ptr, log_n, w_words, inverse, n_rows):
         self._check(lib().kzg_ntt_rows_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
                                               int(bool(inverse)), n_rows))
+
+    def ntt_rows_twist_device(self, d_ptr, log_n, w_words, inverse, n_rows, row_base):
+        self._check(lib().kzg_ntt_rows_twist_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
+                                                    int(bool(inverse)), n_rows, row_base))
+
+    def ntt_columns_plain_device(self, d_ptr, log_n, w_words, inverse, n_cols):
+        self._check(lib().kzg_ntt_columns_plain_device(self._h, _as_vp(d_ptr), log_n, _as_vp(w_words),
+                                                       int(bool(inverse)), n_cols))
 
     def ntt_rows_exchange_device(self, d_src, d_dst, log_n, w_words, inverse, n_rows, world, blocked_out):
         self._check(lib().kzg_ntt_rows_exchange_device(self._h, _as_vp(d_src), _as_vp(d_dst), log_n, _as_vp(w_words),

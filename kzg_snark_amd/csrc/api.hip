@@ -252,6 +252,24 @@ int kzg_ntt_rows_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64
                             inverse ? 1 : 0, 1, n_rows, 0);
 }
 
+int kzg_ntt_rows_twist_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                              uint64_t n_rows, uint64_t row_base) {
+  if (!ctx || !d_data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return ntt_partial_device(c, static_cast<uint32_t*>(d_data), log_n, reinterpret_cast<const uint32_t*>(w),
+                            inverse ? 1 : 0, 2, n_rows, row_base);
+}
+
+int kzg_ntt_columns_plain_device(kzg_ctx* ctx, void* d_data, uint32_t log_n, const uint64_t w[4], int inverse,
+                                 uint64_t n_cols) {
+  if (!ctx || !d_data || !w) return KZG_ERR_ARG;
+  Ctx* c = &ctx->c;
+  KZG_HIP(c, hipSetDevice(c->device));
+  return ntt_partial_device(c, static_cast<uint32_t*>(d_data), log_n, reinterpret_cast<const uint32_t*>(w),
+                            inverse ? 1 : 0, 3, n_cols, 0);
+}
+
 int kzg_ntt_rows_exchange_device(kzg_ctx* ctx, const void* d_src, void* d_dst, uint32_t log_n, const uint64_t w[4],
                                  int inverse, uint64_t n_rows, uint32_t world, int blocked_out) {
   if (!ctx || !d_src || !d_dst || !w) return KZG_ERR_ARG;

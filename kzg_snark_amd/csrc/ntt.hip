@@ -522,21 +522,40 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
   const uint32_t k1 = (log_n + 1) / 2, k2 = log_n - k1;
   const uint64_t N1 = 1ull << k1, N2 = 1ull << k2;
   if (count == 0 || (count & (count - 1))) return set_err(c, KZG_ERR_ARG, "row/column count must be a power of two");
-  if (rows_pass ? count > N1 : (col_base + count > N2)) return set_err(c, KZG_ERR_ARG, "row/column range");
+  {
+    const bool col_pass = rows_pass == 0 || rows_pass == 3;
+    const uint64_t first = (rows_pass == 0 || rows_pass == 2) ? col_base : 0;       // global index of the first line
+    if (first + count > (col_pass ? N2 : N1)) return set_err(c, KZG_ERR_ARG, "row/column range");
+  }
   NttDomain* dom = nullptr;
   int rc = get_domain<F>(c, log_n, w_words, inverse, &dom);
   if (rc) return rc;
   uint32_t lc = 0;
   while ((1ull << (lc + 1)) <= count) ++lc;
+  // rows_pass: 0 columns + twist, 1 rows, 2 rows + twist by (global row) x (output index), 3 columns without twist.
+  // 2 then 3 is the transform taken the other way round -- input in the TRANSPOSED layout (row rho of the [N1][N2]
+  // matrix holds the indices b N1 + rho), output in natural order: X[alpha N2 + beta] = sum_rho w^(rho alpha N2)
+  // [ w^(rho beta) sum_b x[b N1 + rho] w^(b beta N1) ].  That identity needs w^n = 1 (the decimation-in-time form of
+  // modes 0 / 1 holds for every w, this one for the roots of unity the provers pass), so mode 2 checks it.
+  const bool cols = rows_pass == 0 || rows_pass == 3, twisted = rows_pass == 0 || rows_pass == 2;
+  if (rows_pass == 2 && !dom->d_twA)
+    return set_err(c, KZG_ERR_ARG, "kzg_ntt_rows_twist_device needs the twist factor tables (KZG_NTT_TWIST_TABLE is set)");
+  if (rows_pass == 2) {
+    using Fd = Field<F>;
+    Fe<F> t = Fd::to_mont(Fd::from_words(w_words));
+    for (uint32_t q = 0; q + 1 < log_n; ++q) t = Fd::mul(t, t);                 // w^(n/2)
+    if (!Fd::is_zero(Fd::add(t, Fd::one())))
+      return set_err(c, KZG_ERR_ARG, "kzg_ntt_rows_twist_device: w must be a primitive 2^log_n-th root of unity");
+  }
   NttPassArgs a{};
   a.ld_shift = a.st_shift = 31;
   a.src = d_data; a.dst = d_dst ? d_dst : d_data; a.stage = dom->d_stage; a.kmax = dom->kmax; a.h = 0; a.batch_stride = 0;
   a.pair_tiles = 0;
   uint64_t tiles;
-  if (!rows_pass) {
+  if (cols) {
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k1, lc);
-    a.twist = dom->d_twist; a.twist_pitch = N2; a.scale = nullptr; a.col_base = col_base;
-    a.twA = dom->d_twist ? nullptr : dom->d_twA; a.twB = dom->d_twB; a.h = dom->h;
+    a.twist = twisted ? dom->d_twist : nullptr; a.twist_pitch = N2; a.scale = nullptr; a.col_base = col_base;
+    a.twA = (twisted && !dom->d_twist) ? dom->d_twA : nullptr; a.twB = dom->d_twB; a.h = dom->h;
     a.k = k1; a.logC = logC; a.c_fast_load = 1; a.c_fast_store = 1;
     a.ld_line = 1; a.ld_pos = count; a.tile_ld = 1ull << logC;
     a.st_line = 1; a.st_pos = count; a.tile_st = 1ull << logC;
@@ -544,6 +563,7 @@ int ntt_partial_t(Ctx* c, uint32_t* d_data, uint32_t log_n, const uint32_t* w_wo
   } else {
     const uint32_t logC = std::min<uint32_t>(TILE_LOG - k2, lc);
     a.twist = nullptr; a.twist_pitch = 0; a.scale = dom->d_scale; a.col_base = 0;
+    if (twisted) { a.twA = dom->d_twA; a.twB = dom->d_twB; a.h = dom->h; a.col_base = col_base; a.scale = nullptr; }
     a.k = k2; a.logC = logC; a.c_fast_load = 0; a.c_fast_store = 0;
     a.ld_line = N2; a.ld_pos = 1; a.tile_ld = N2 << logC;
     a.st_line = N2; a.st_pos = 1; a.tile_st = N2 << logC;

@@ -417,6 +417,13 @@ class GpuNttOps:
         self.ctx.ntt_rows_exchange_device(recv.data_ptr(), out.data_ptr(), self.log_n, self.w, self.inverse, n_rows,
                                           world, blocked)
 
+    def rows_twist(self, rows, row_base):
+        """[n_rows][N2] rows of the transposed layout (global rows row_base ..): row transforms + twist, in place"""
+        self.ctx.ntt_rows_twist_device(rows.data_ptr(), self.log_n, self.w, self.inverse, rows.shape[0], row_base)
+
+    def columns_plain(self, M):
+        self.ctx.ntt_columns_plain_device(M.data_ptr(), self.log_n, self.w, self.inverse, M.shape[1])
+
 
 # =====================================================================================================
 # Pieces of the VECTOR-sharded prover (kzg_snark_amd/plonk_sharded.py): tensor collectives and the three
@@ -472,8 +479,9 @@ class ShardedTransforms:
                                            range of n/G per rank) -> its transform in the TRANSPOSED layout of the
                                            2^log_big four-step (two all-to-alls; only the n/N2' non-zero rows of the
                                            N1' x N2' view travel in the first one);
-      T_to_natural(x, log_big, w, inverse) transposed layout in -> contiguous range out: one all-to-all + a local
-                                           transpose bring the data into range order, then `natural`.
+      T_to_natural(x, log_big, w, inverse) transposed layout in -> contiguous range out: the four-step taken the other
+                                           way round (row transforms + twist, all-to-all, column transforms,
+                                           all-to-all); needs a primitive root w.
 
     The transposed layout of a 2^L transform over G ranks: rank g holds [R1][N2] (R1 = N1 / G), element (t, b) being
     index b * N1 + g * R1 + t (transposed_index).  Element-wise work does not care about the order as long as every
@@ -614,12 +622,16 @@ class ShardedTransforms:
         R1, W = N1 // G, N2 // G
         assert x.shape[0] == R1 * N2
         if self._distributed(log_big):
+            # the transform taken the other way round: local row transforms + twist, rows -> columns, column
+            # transforms, columns -> rows: two all-to-alls (four when the data is first brought into range order)
             d = self._dntt(log_big, w, inverse)
-            send = x.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()       # block h: my rows, rank h's outputs
-            got = d.exchange(send)                                            # [G][R1][W]: rows s * R1 + t, my W columns
-            nat = got.view(N1, W, 4).permute(1, 0, 2).contiguous().view(W * N1, 4)
-            self.exchanges += 4
-            return d.transform(nat, log_big, layout="natural")
+            rows = x.clone().view(R1, N2, 4)
+            d.ops.rows_twist(rows, g * R1)
+            M = d.exchange(rows.view(R1, G, W, 4).permute(1, 0, 2, 3).contiguous()).view(N1, W, 4)   # my W columns, whole
+            d.ops.columns_plain(M)                                        # element (alpha, beta) = X[alpha N2 + beta]
+            recv = d.exchange(M.view(G, R1, W, 4))                        # block h: my rows alpha, rank h's columns
+            self.exchanges += 2
+            return recv.permute(1, 0, 2, 3).contiguous().view(R1 * N2, 4)
         self.exchanges += 1
         parts = all_gather_tensor(x, self.group).view(G, R1 * N2, 4)
         full = torch.empty((1 << log_big, 4), dtype=x.dtype, device=x.device)

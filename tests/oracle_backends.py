@@ -69,6 +69,35 @@ class OracleNttOps:
         put(out, res)
 
 
+def _rows_twist(self, rows, row_base):
+    """mode of kzg_ntt_rows_twist_device: N2-point transforms along the rows, output (rho, beta) times w^(rho beta)"""
+    R, N2 = rows.shape[0], rows.shape[1]
+    vals = ints_of(rows)
+    root = pow(self.w, 1 << self.k1, self.r)
+    out = [0] * (R * N2)
+    for t in range(R):
+        tr = O.fft_ff(vals[t * N2:(t + 1) * N2], root, self.r)
+        for b in range(N2):
+            out[t * N2 + b] = tr[b] * pow(self.w, (row_base + t) * b, self.r) % self.r * self.scale % self.r
+    put(rows, out)
+
+
+def _columns_plain(self, M):
+    N1, W = M.shape[0], M.shape[1]
+    vals = ints_of(M)
+    root = pow(self.w, 1 << self.k2, self.r)
+    out = [0] * (N1 * W)
+    for c in range(W):
+        col = O.fft_ff([vals[t * W + c] for t in range(N1)], root, self.r)
+        for t in range(N1):
+            out[t * W + c] = col[t]
+    put(M, out)
+
+
+OracleNttOps.rows_twist = _rows_twist
+OracleNttOps.columns_plain = _columns_plain
+
+
 class OracleShardBackend:
     min_distributed_log = 2            # the all-to-all choreography even at 16 elements
 

@@ -423,3 +423,38 @@ def test_transform_beside_a_commit_in_flight(native, curve):
                     ctx.set_tuning("ntt_tile_log", 0)
                 assert np.array_equal(forced.cpu().numpy().view(np.uint64), want), (log_n, inverse, tile_log)
     srs.close()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_transposed_to_natural_passes(native, curve):
+    """kzg_ntt_rows_twist_device + kzg_ntt_columns_plain_device: the four-step taken the other way round -- input in
+    the transposed layout (row rho holds the elements b N1 + rho), output in natural order -- equals the whole
+    transform (fft_ff.py:15-37 / :39-58) for a primitive root, forward and inverse, 2^13 (odd split) and 2^16; on a
+    row range with its base; a w that is not a primitive root is refused."""
+    import torch
+    cv = O.curve(curve)
+    ctx = native.get_context(curve)
+    rs = np.random.RandomState(5)
+    for log_n in (13, 16):
+        n = 1 << log_n
+        k1 = (log_n + 1) // 2
+        N1, N2 = 1 << k1, 1 << (log_n - k1)
+        w = cv.root_of_unity(n)
+        ww = native.int_to_words(w)
+        raw = _plant_edge_values(_uniform_below_r(rs, n, cv.r), cv.r, native)
+        for inverse in (False, True):
+            want = raw.copy()
+            ctx.ntt(want, log_n, ww, inverse)                                           # the whole transform
+            x = torch.from_numpy(raw.view(np.int64)).to("cuda:0")
+            T = x.view(N2, N1, 4).permute(1, 0, 2).contiguous()                         # T[rho][b] = x[b N1 + rho]
+            torch.cuda.synchronize()             # torch's stream wrote T; the context runs on a stream of its own
+            half = N1 // 2
+            ctx.ntt_rows_twist_device(T.data_ptr(), log_n, ww, inverse, half, 0)        # two row ranges, as two ranks would
+            ctx.ntt_rows_twist_device(T.data_ptr() + half * N2 * 32, log_n, ww, inverse, half, half)
+            M = T.view(N1, N2, 4)
+            ctx.ntt_columns_plain_device(M.data_ptr(), log_n, ww, inverse, N2)
+            ctx.synchronize()
+            assert np.array_equal(M.cpu().numpy().view(np.uint64).reshape(n, 4), want), (log_n, inverse)
+    with pytest.raises(native.NativeError):
+        t = torch.zeros((1 << 13, 4), dtype=torch.int64, device="cuda:0")
+        ctx.ntt_rows_twist_device(t.data_ptr(), 13, native.int_to_words(12345), False, 128, 0)

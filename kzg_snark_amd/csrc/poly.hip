@@ -154,7 +154,7 @@ constexpr uint32_t TILE_DIRECT_MAX = 1024;             // up to this many tiles 
 #endif
 // Issue priority of the two tile kernels.  Beside an accumulate kernel they hold a wave slot and ~110 VGPRs per SIMD
 // that the reduce stage's 168-VGPR waves then cannot get: at priority 0 the combination of opening p + 1 sat there for
-// 1.4 ms and rc1 / rc2 / prep_binsort stretched 4-17x (gpurun_out/trace_open_a); raised, it is gone after 0.48 ms:
+// 1.4 ms and rc1 / rc2 / prep_binsort stretched 4-17x (profiles/r04_open_async_timeline_prio0.txt); raised, it is gone after 0.48 ms:
 // 448 vs 430 pipelined opens/s, same box, alternating (profiles/r04_open_async_ab.txt).
 #ifndef KZG_TILE_PRIO
 #define KZG_TILE_PRIO 3

@@ -143,3 +143,42 @@ def test_default_device_follows_the_environment(monkeypatch):
         assert _native.default_device() == 0
     monkeypatch.setenv("KZG_MI355X_DEVICE", "5")
     assert _native.default_device() == 5
+
+
+@pytest.mark.gpu
+def test_tuning_keys_and_values_are_checked():
+    """kzg_ctx_set_tuning refuses unknown keys and values outside what the kernels are built for; 0 restores the
+    library's own choice.  (Results never depend on a tuning value: tests/test_kzg_gpu.py, tests/test_ntt_gpu.py.)"""
+    from kzg_snark_amd import _native
+    ctx = _native.get_context("bls12_381")
+    for key, bad in (("ntt_tile_log", 7), ("ntt_tile_log", 13), ("open_tile_threads", 64), ("open_tile_threads", 512),
+                     ("open_direct_tiles", -1), ("no_such_key", 1)):
+        with pytest.raises(_native.NativeError):
+            ctx.set_tuning(key, bad)
+    for key, ok in (("ntt_tile_log", 10), ("open_tile_threads", 128), ("open_direct_tiles", 5)):
+        ctx.set_tuning(key, ok)
+        ctx.set_tuning(key, 0)
+
+
+@pytest.mark.gpu
+def test_partial_transform_passes_check_their_ranges():
+    """The local halves of the distributed transform refuse sizes the tiled kernels do not take (log_n <= 12), counts
+    that are not powers of two, and line ranges beyond the matrix -- before anything is launched."""
+    import torch
+    from kzg_snark_amd import _native
+    ctx = _native.get_context("bls12_381")
+    r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    buf = torch.zeros((1 << 14, 4), dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    w14, w12 = _native.int_to_words(pow(7, (r - 1) >> 14, r)), _native.int_to_words(pow(7, (r - 1) >> 12, r))
+    p = buf.data_ptr()
+    for call in (lambda: ctx.ntt_columns_device(p, 12, w12, False, 64, 0),              # single-tile size
+                 lambda: ctx.ntt_columns_device(p, 14, w14, False, 96, 0),              # not a power of two
+                 lambda: ctx.ntt_columns_device(p, 14, w14, False, 64, 96),             # columns 96 .. 159 of 128
+                 lambda: ctx.ntt_rows_device(p, 14, w14, False, 256),                   # more rows than the matrix has
+                 lambda: ctx.ntt_rows_twist_device(p, 14, w14, False, 64, 96),          # rows 96 .. 159 of 128
+                 lambda: ctx.ntt_columns_plain_device(p, 14, w14, False, 256)):         # more columns than it has
+        with pytest.raises(_native.NativeError):
+            call()
+    ctx.ntt_rows_twist_device(p, 14, w14, False, 64, 64)                                # rows 64 .. 127: fine
+    ctx.synchronize()
